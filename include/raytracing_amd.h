@@ -1,0 +1,189 @@
+/*
+ * raytracing_amd.h — C ABI of the MI355X (gfx950) hot path of the Neuroglial/RayTracing renderer:
+ * KD-tree traversal + watertight ray/triangle intersection + the Path / Whitted bounce loop.
+ *
+ * Boundary: the reference has no FFI; its extension seam is the Renderer object
+ * (reference src/core/Render/Render.h:20-21, registered through AURORA_REGISTER_CLASS,
+ * src/core/Object/Object.h:290-300). A Renderer subclass flattens the host scene into
+ * rt_scene_desc and calls the entry points below from Renderer::render().
+ *
+ * Conventions: every entry point returns 0 on success or a negative rt_status, never throws or
+ * aborts. Unless a name ends in _dev, pointers are HOST memory owned by the caller; the library
+ * copies what it needs before returning. *_dev entry points take DEVICE pointers on the context's
+ * GPU (for callers that keep rays / film buffers resident in HBM). One context per GPU per
+ * process; a context is single-caller (not thread-safe), like the reference's render loop
+ * (src/RayTracing.cpp:32-33).
+ */
+#ifndef RAYTRACING_AMD_H
+#define RAYTRACING_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,
+    RT_ERR_NO_DEVICE = -2,
+    RT_ERR_HIP = -3,
+    RT_ERR_NO_SCENE = -4,
+    RT_ERR_UNSUPPORTED = -5,
+    RT_ERR_NO_CAMERA = -6
+} rt_status;
+
+/* Shape kinds (reference: ATriangleShape "Triangle" TriangleShape.cpp:120, ASphereShape "Sphere" SphereShape.cpp:10). */
+enum { RT_SHAPE_TRIANGLE = 0, RT_SHAPE_SPHERE = 1 };
+
+/* Material kinds. LAMBERTIAN = LambertianMaterial (Material/LambertianMaterial.cpp:19-28),
+ * MIRROR = MirrorMaterial (Material/MirrorMaterial.cpp:19-29). GLASS has no reference material: it is
+ * the pair {ASpecularReflection(R, AFresnelDielectric(1, eta)), ASpecularTransmission(T, 1, eta, Radiance)}
+ * built from the reference's BxDFs (Render/BSDF.h:134-176). */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_MIRROR = 1, RT_MAT_GLASS = 2 };
+
+typedef struct rt_material {
+    int32_t type;      /* RT_MAT_* */
+    float rgb[3];      /* Kr (Lambertian / Mirror), R = T (Glass) */
+    float eta;         /* Glass only */
+} rt_material;
+
+/* One DiffuseAreaLight per emissive primitive (reference Object/Entity.cpp:169-176, Render/Light.h:95-133). */
+typedef struct rt_light {
+    int32_t prim_id;
+    float emit[3];     /* m_Lemit */
+    int32_t two_sided; /* m_twoSided */
+} rt_light;
+
+/*
+ * Flattened scene. The KD-tree arrays are the reference's own, verbatim
+ * (KdTree::m_nodes / m_hitableIndices / m_bounds, Accelerators/KDTree.h:40-45):
+ *   nodes[2*i+0] = float split | int oneHitable | int indicesOffset   (KDTree.cpp:29-34)
+ *   nodes[2*i+1] = low 2 bits: split axis 0,1,2 or 3 = leaf; high 30 bits: aboveChild (interior)
+ *                  or nHitables (leaf)                                (KDTree.cpp:38-43)
+ *   the below child of interior node i is node i+1.
+ * Primitive i is the reference's m_hitables[i]; triangles carry world-space vertices
+ * (TriangleMesh bakes objectToWorld at load, Shape/TriangleShape.cpp:100-111).
+ */
+typedef struct rt_scene_desc {
+    uint32_t n_nodes;
+    const uint32_t *nodes;       /* 2 * n_nodes words */
+    uint32_t n_leaf_idx;
+    const int32_t *leaf_idx;     /* may be NULL when n_leaf_idx == 0 */
+    float bounds[6];             /* pMin.xyz, pMax.xyz */
+    uint32_t n_prims;
+    const uint8_t *shape_type;   /* n_prims, RT_SHAPE_*; NULL = all triangles */
+    const float *tri_p;          /* n_prims * 9: p0, p1, p2 */
+    const float *tri_n;          /* n_prims * 9: n0, n1, n2 or NULL when no primitive has normals */
+    const uint8_t *tri_has_n;    /* n_prims or NULL (= all have normals iff tri_n != NULL) */
+    const float *tri_uv;         /* n_prims * 6 or NULL: default (0,0),(1,0),(1,1) (TriangleShape.cpp:396-401) */
+    const int32_t *material_id;  /* n_prims */
+    const int32_t *light_id;     /* n_prims, -1 = not emissive */
+    uint32_t n_materials;
+    const rt_material *materials;
+    uint32_t n_lights;
+    const rt_light *lights;      /* order = Scene::m_lights (Scene/SceneParser.cpp:166-172) */
+} rt_scene_desc;
+
+enum { RT_INTEGRATOR_PATH = 0, RT_INTEGRATOR_WHITTED = 1 };
+
+/* RNG layout. REFERENCE_TILE_STREAM reproduces the reference's sampler exactly: one PCG32 stream per
+ * 16x16 tile seeded with the tile index, consumed serially pixel by pixel, sample by sample
+ * (Render/Render.cpp:32-92, Render/Sampler.cpp:174-179). COUNTER gives every camera sample its own
+ * PCG32 stream (sequence = (pixel index * spp_total + sample index) ^ seed scrambling, see rt_render). */
+enum { RT_RNG_COUNTER = 0, RT_RNG_REFERENCE_TILE_STREAM = 1 };
+
+typedef struct rt_render_params {
+    int32_t integrator;    /* RT_INTEGRATOR_* */
+    int32_t spp_total;     /* Sampler "SPP": samples per pixel of the whole job */
+    int32_t spp_begin;     /* this call renders sample indices [spp_begin, spp_end) — the multi-GPU shard */
+    int32_t spp_end;
+    int32_t max_depth;     /* Renderer "Depth" (Render.cpp:321,458) */
+    float rr_threshold;    /* PathRenderer::m_rrThreshold, 1 in the reference (Render.cpp:322) */
+    int32_t rng_mode;      /* RT_RNG_* */
+    uint64_t seed;         /* COUNTER mode only */
+    int32_t spp_per_pass;  /* wavefront batch: samples per pixel in flight at once; 0 = library default */
+    int32_t collect_stats; /* nonzero: count nodes / leaves / triangle tests per ray (slow path) */
+} rt_render_params;
+
+typedef struct rt_stats {
+    /* rays traced since rt_reset_stats: one ray = one KdTree::hit call of either flavour */
+    uint64_t rays_closest;     /* extend + MIS-probe rays */
+    uint64_t rays_any;         /* shadow rays */
+    uint64_t camera_samples;
+    /* traversal counters (only advanced when collect_stats != 0) */
+    uint64_t n_interior;
+    uint64_t n_leaf;
+    uint64_t n_leaf_idx;
+    uint64_t n_tri_tests;
+    uint64_t counted_rays;
+    /* HIP-event time of the closest-hit (extend) kernel launches since rt_reset_stats */
+    uint64_t extend_launches;
+    double extend_ms;
+    uint64_t extend_rays;      /* rays processed by those launches */
+    double render_ms;          /* wall time of rt_render* calls (host clock, device-synchronised) */
+} rt_stats;
+
+/* Library / context ------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device_id`. Fails with RT_ERR_NO_DEVICE when no GPU is visible:
+ * there is no CPU fallback. */
+int rt_create(int device_id, rt_context **out_ctx);
+void rt_destroy(rt_context *ctx);
+const char *rt_last_error(const rt_context *ctx);   /* ctx may be NULL: last creation error */
+const char *rt_version(void);
+
+/* Scene / camera ------------------------------------------------------------------------------ */
+
+/* Replaces what the reference does implicitly by holding Scene / KdTree objects
+ * (Scene/Scene.h:33-37, Accelerators/KDTree.h:36-45). Copies everything to the device. */
+int rt_upload_scene(rt_context *ctx, const rt_scene_desc *scene);
+
+/* Camera::m_cameraToWorld and AProjectiveCamera::m_rasterToCamera (Camera/Camera.h:42,59), column-major
+ * as glm stores them; film resolution and the sample bounds [x0,x1) x [y0,y1) of Film::getSampleBounds
+ * (Object/Film.cpp:79-85). Replaces Camera::castingRay (Camera/Camera.cpp:87-95) on the device. */
+int rt_set_camera(rt_context *ctx, const float raster_to_camera[16], const float camera_to_world[16],
+                  int width, int height, const int sample_bounds[4]);
+
+/* Batch tracing --------------------------------------------------------------------------------- */
+
+/* Closest hit: KdTree::hit(ray, isect) (Accelerators/KDTree.cpp:385-490) over n rays. d is used as
+ * given (callers pass the normalised direction a reference Ray holds, Utils/Math.h:326-327).
+ * Outputs: prim_id (-1 = miss), t (= ray.m_tMax after the call), bary (b0,b1,b2 of
+ * Shape/TriangleShape.cpp:361-363). Any output pointer may be NULL. */
+int rt_trace_closest(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d_xyz,
+                     const float *tmax, int32_t *prim_id, float *t, float *bary3);
+/* Any hit: KdTree::hit(ray) (Accelerators/KDTree.cpp:284-383). occluded[i] = 1 when something is hit. */
+int rt_trace_any(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d_xyz,
+                 const float *tmax, uint8_t *occluded);
+/* Same, all pointers in device memory, asynchronous on the context's stream (call rt_synchronize). */
+int rt_trace_closest_dev(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d_xyz,
+                         const float *tmax, int32_t *prim_id, float *t, float *bary3);
+int rt_trace_any_dev(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d_xyz,
+                     const float *tmax, uint8_t *occluded);
+
+/* Rendering --------------------------------------------------------------------------------------- */
+
+/* Replaces SamplerRenderer::render's sample loop (Render/Render.cpp:29-98) with PathRenderer::Li
+ * (Render.cpp:348-449) or WhittedRenderer::Li (Render.cpp:473-532). Adds, for every film pixel
+ * (row-major, width*height), the box-filtered sums FilmTile::addSample keeps
+ * (Object/Film.h:111-155): rgb_sum += L * weight, weight_sum += weight. Output buffers are
+ * ACCUMULATED INTO (zero them for a fresh render). Host variant blocks and copies back. */
+int rt_render(rt_context *ctx, const rt_render_params *params, float *rgb_sum, float *weight_sum);
+/* Device variant: rgb_sum_dev / weight_sum_dev live on the context's GPU; returns after the work is
+ * queued on the context's stream (rt_synchronize to wait). */
+int rt_render_dev(rt_context *ctx, const rt_render_params *params, float *rgb_sum_dev, float *weight_sum_dev);
+
+int rt_synchronize(rt_context *ctx);
+/* The hipStream_t the context launches on (as void*), for callers that record their own events. */
+void *rt_stream(rt_context *ctx);
+
+int rt_get_stats(rt_context *ctx, rt_stats *out);
+int rt_reset_stats(rt_context *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACING_AMD_H */

@@ -1,0 +1,1098 @@
+/*
+ * oracle.cpp — CPU restatement of the reference's hot path. TEST INFRASTRUCTURE ONLY: it is the
+ * checker the HIP kernels are compared against (tests/, __graft_entry__.smoke()) and the CPU baseline
+ * timed by bench.py; nothing in raytracing_amd/ may include, link or call it.
+ *
+ * It follows the reference function by function, with the same float operation order (scalar glm
+ * 0.9.9.8 semantics; build with -ffp-contract=off):
+ *   KD traversal        reference src/core/Accelerators/KDTree.cpp:284-490, Utils/Math.h:572-601
+ *   triangle test       src/core/Shape/TriangleShape.cpp:153-453
+ *   shape sampling      src/core/Shape/Shape.cpp:28-67
+ *   BSDF / BxDFs        src/core/Render/BSDF.h:24-72, BSDF.cpp:9-246
+ *   materials           src/core/Material/LambertianMaterial.cpp:19-28, MirrorMaterial.cpp:19-29
+ *   area light          src/core/Render/Light.h:105-108, Light.cpp:28-31,109-128
+ *   light selection     src/core/Utils/LightDistrib.h:14-83, Utils/Math.h:638-657
+ *   sampling warps, RNG src/core/Render/Sampler.cpp:120-148,161-179, Sampler.h:71-89, Utils/Math.h:694-790
+ *   integrators         src/core/Render/Render.cpp:106-152,189-312,348-449,473-532
+ *   render loop, film   src/core/Render/Render.cpp:14-104, Object/Film.h:111-155, Camera/Camera.cpp:87-95
+ *
+ * Pinning: the reference ships no tests or golden vectors for this path, and its sources cannot be
+ * compiled in this build's environment without its vendored cmake projects (glog, assimp), so the
+ * oracle is pinned by the artefacts the reference does hold and publish: the 800x800 512-spp
+ * cornellBox.png (tests compare an oracle render against it) and the KD-tree / traversal statistics
+ * of the reference recorded by the survey. Results that depend on libm's cosf/sinf are "parity unpinned".
+ */
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/raytracing_amd.h"
+#include "oracle.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// math (glm scalar semantics)
+// ------------------------------------------------------------------------------------------------
+struct vec3 {
+    float x = 0, y = 0, z = 0;
+    vec3() = default;
+    vec3(float a, float b, float c) : x(a), y(b), z(c) {}
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    float &operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline vec3 operator+(const vec3 &a, const vec3 &b) { return vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline vec3 operator-(const vec3 &a, const vec3 &b) { return vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline vec3 operator-(const vec3 &a) { return vec3(-a.x, -a.y, -a.z); }
+inline vec3 operator*(const vec3 &a, float s) { return vec3(a.x * s, a.y * s, a.z * s); }
+inline vec3 operator*(float s, const vec3 &a) { return vec3(s * a.x, s * a.y, s * a.z); }
+inline vec3 operator/(const vec3 &a, float s) { return vec3(a.x / s, a.y / s, a.z / s); }
+inline float dot(const vec3 &a, const vec3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float absDot(const vec3 &a, const vec3 &b) { return std::fabs(dot(a, b)); }
+inline vec3 cross(const vec3 &a, const vec3 &b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+inline float lengthSquared(const vec3 &a) { return dot(a, a); }
+inline float length(const vec3 &a) { return std::sqrt(dot(a, a)); }
+inline vec3 normalize(const vec3 &a) { return a * (1.0f / std::sqrt(dot(a, a))); }
+inline float gmin(float x, float y) { return (y < x) ? y : x; }
+inline float gmax(float x, float y) { return (x < y) ? y : x; }
+inline vec3 vabs(const vec3 &a) { return vec3(std::fabs(a.x), std::fabs(a.y), std::fabs(a.z)); }
+inline float maxComponent(const vec3 &v) { return gmax(v.x, gmax(v.y, v.z)); }
+inline int maxDimension(const vec3 &v) { return (v.x > v.y) ? ((v.x > v.z) ? 0 : 2) : ((v.y > v.z) ? 1 : 2); }
+inline vec3 permute(const vec3 &v, int x, int y, int z) { return vec3(v[x], v[y], v[z]); }
+inline vec3 faceforward(const vec3 &n, const vec3 &v) { return (dot(n, v) < 0.f) ? -n : n; }
+inline void coordinateSystem(const vec3 &v1, vec3 &v2, vec3 &v3) {
+    if (std::fabs(v1.x) > std::fabs(v1.y)) v2 = vec3(-v1.z, 0, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+    else v2 = vec3(0, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+    v3 = cross(v1, v2);
+}
+
+constexpr float kShadowEpsilon = 0.0001f;
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
+constexpr float kPiOver2 = 1.57079632679489661923f;
+constexpr float kPiOver4 = 0.78539816339744830961f;
+constexpr float kInfinity = std::numeric_limits<float>::infinity();
+constexpr float kMachineEpsilon = std::numeric_limits<float>::epsilon() * 0.5f;
+constexpr float kOneMinusEpsilon = 0.99999994f;
+inline float gammaErr(int n) { return (n * kMachineEpsilon) / (1 - n * kMachineEpsilon); }
+
+struct Spectrum {
+    float c[3];
+    Spectrum(float v = 0.f) { c[0] = c[1] = c[2] = v; }
+    Spectrum(float r, float g, float b) { c[0] = r; c[1] = g; c[2] = b; }
+    bool isBlack() const { return c[0] == 0. && c[1] == 0. && c[2] == 0.; }
+    bool hasNaNs() const { return std::isnan(c[0]) || std::isnan(c[1]) || std::isnan(c[2]); }
+    float luminance() const { return 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]; }
+    float maxComponentValue() const { float m = c[0]; m = gmax(m, c[1]); m = gmax(m, c[2]); return m; }
+    Spectrum &operator+=(const Spectrum &s) { for (int i = 0; i < 3; ++i) c[i] += s.c[i]; return *this; }
+    Spectrum &operator*=(const Spectrum &s) { for (int i = 0; i < 3; ++i) c[i] *= s.c[i]; return *this; }
+    Spectrum &operator*=(float a) { for (int i = 0; i < 3; ++i) c[i] *= a; return *this; }
+    Spectrum &operator/=(float a) { for (int i = 0; i < 3; ++i) c[i] /= a; return *this; }
+};
+inline Spectrum operator*(const Spectrum &a, const Spectrum &b) { return Spectrum(a.c[0] * b.c[0], a.c[1] * b.c[1], a.c[2] * b.c[2]); }
+inline Spectrum operator*(const Spectrum &a, float s) { return Spectrum(a.c[0] * s, a.c[1] * s, a.c[2] * s); }
+inline Spectrum operator*(float s, const Spectrum &a) { return a * s; }
+inline Spectrum operator/(const Spectrum &a, float s) { return Spectrum(a.c[0] / s, a.c[1] / s, a.c[2] / s); }
+inline Spectrum operator-(const Spectrum &a, const Spectrum &b) { return Spectrum(a.c[0] - b.c[0], a.c[1] - b.c[1], a.c[2] - b.c[2]); }
+
+// PCG32 (Utils/Math.h:690-790)
+struct Rng {
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    void setSequence(uint64_t initseq) {
+        state = 0u;
+        inc = (initseq << 1u) | 1u;
+        uniformUInt32();
+        state += 0x853c49e6748fea9bULL;
+        uniformUInt32();
+    }
+    uint32_t uniformUInt32() {
+        uint64_t oldstate = state;
+        state = oldstate * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+        uint32_t rot = (uint32_t)(oldstate >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    float uniformFloat() { return gmin(kOneMinusEpsilon, float(uniformUInt32() * 2.3283064365386963e-10f)); }
+};
+struct Sampler {
+    Rng rng;
+    uint64_t draws = 0;
+    float get1D() { ++draws; return rng.uniformFloat(); }
+    void get2D(float u[2]) { draws += 2; u[0] = rng.uniformFloat(); u[1] = rng.uniformFloat(); }
+};
+
+inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------------------------
+struct Ray {
+    vec3 o, d;
+    mutable float tMax = kInfinity;
+    Ray() = default;
+    Ray(const vec3 &o_, const vec3 &d_, float t = kInfinity) : o(o_), d(normalize(d_)), tMax(t) {}   // Math.h:326-327
+};
+
+struct Interaction {
+    vec3 p, wo, n;
+    Ray spawnRay(const vec3 &d) const { return Ray(p, d, kInfinity); }                       // Interaction.h:20-24
+    Ray spawnRayTo(const Interaction &it) const { return Ray(p, it.p - p, 1 - kShadowEpsilon); }   // :34-40
+};
+struct SurfaceInteraction : Interaction {
+    vec3 dpdu, dpdv;
+    int prim = -1;
+    float b[3] = {0, 0, 0};
+};
+
+struct Scene {
+    std::vector<uint32_t> nodes;
+    std::vector<int32_t> leafIdx;
+    vec3 bmin, bmax;
+    uint32_t nPrims = 0;
+    std::vector<float> triP, triN, triUV;
+    std::vector<uint8_t> hasN;
+    bool hasUV = false;
+    std::vector<int32_t> materialId, lightId;
+    std::vector<rt_material> materials;
+    std::vector<rt_light> lights;
+    std::vector<float> lightArea;
+    // light selection distribution (UniformLightDistribution)
+    std::vector<float> func, cdf;
+    float funcInt = 0;
+    // camera
+    float r2c[16], c2w[16];
+    int width = 0, height = 0, sb[4] = {0, 0, 0, 0};
+    bool hasCamera = false;
+
+    vec3 P(int prim, int k) const { const float *p = &triP[9 * prim + 3 * k]; return vec3(p[0], p[1], p[2]); }
+    vec3 N(int prim, int k) const { const float *p = &triN[9 * prim + 3 * k]; return vec3(p[0], p[1], p[2]); }
+};
+
+struct Counters {
+    uint64_t interior = 0, leaf = 0, leafIdx = 0, tri = 0, rays = 0, maxStack = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// triangle (Shape/TriangleShape.cpp)
+// ------------------------------------------------------------------------------------------------
+float triArea(const Scene &s, int prim) {
+    vec3 p0 = s.P(prim, 0), p1 = s.P(prim, 1), p2 = s.P(prim, 2);
+    return (float)(0.5 * length(cross(p1 - p0, p2 - p0)));
+}
+
+// The ray/triangle test shared by both hit flavours (:178-282 and :284-385). Returns false on reject.
+bool triTest(const Scene &s, int prim, const Ray &ray, float &tOut, float bOut[3]) {
+    vec3 p0 = s.P(prim, 0), p1 = s.P(prim, 1), p2 = s.P(prim, 2);
+    vec3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
+    int kz = maxDimension(vabs(ray.d));
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    vec3 d = permute(ray.d, kx, ky, kz);
+    p0t = permute(p0t, kx, ky, kz);
+    p1t = permute(p1t, kx, ky, kz);
+    p2t = permute(p2t, kx, ky, kz);
+    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double p2txp1ty = (double)p2t.x * (double)p1t.y;
+        double p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y;
+        double p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y;
+        double p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < ray.tMax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > ray.tMax * det)) return false;
+    float invDet = 1 / det;
+    float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    float t = tScaled * invDet;
+    float maxZt = maxComponent(vabs(vec3(p0t.z, p1t.z, p2t.z)));
+    float deltaZ = gammaErr(3) * maxZt;
+    float maxXt = maxComponent(vabs(vec3(p0t.x, p1t.x, p2t.x)));
+    float maxYt = maxComponent(vabs(vec3(p0t.y, p1t.y, p2t.y)));
+    float deltaX = gammaErr(5) * (maxXt + maxZt);
+    float deltaY = gammaErr(5) * (maxYt + maxZt);
+    float deltaE = 2 * (gammaErr(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = maxComponent(vabs(vec3(e0, e1, e2)));
+    float deltaT = 3 * (gammaErr(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * std::fabs(invDet);
+    if (t <= deltaT) return false;
+    tOut = t;
+    bOut[0] = b0; bOut[1] = b1; bOut[2] = b2;
+    return true;
+}
+
+// Surface part of the closest-hit flavour (:387-452). Returns false for a degenerate triangle (:419-420).
+bool triSurface(const Scene &s, int prim, const Ray &ray, const float b[3], SurfaceInteraction &isect) {
+    vec3 p0 = s.P(prim, 0), p1 = s.P(prim, 1), p2 = s.P(prim, 2);
+    float uv[3][2];
+    if (s.hasUV) {
+        for (int k = 0; k < 3; ++k) { uv[k][0] = s.triUV[6 * prim + 2 * k]; uv[k][1] = s.triUV[6 * prim + 2 * k + 1]; }
+    } else {
+        uv[0][0] = 0; uv[0][1] = 0; uv[1][0] = 1; uv[1][1] = 0; uv[2][0] = 1; uv[2][1] = 1;
+    }
+    float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]}, duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
+    vec3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+    bool degenerateUV = std::fabs(determinant) < 1e-8;
+    vec3 dpdu, dpdv;
+    if (!degenerateUV) {
+        float invdet = 1 / determinant;
+        dpdu = (duv12[1] * dp02 - duv02[1] * dp12) * invdet;
+        dpdv = (-duv12[0] * dp02 + duv02[0] * dp12) * invdet;
+    }
+    if (degenerateUV || lengthSquared(cross(dpdu, dpdv)) == 0) {
+        vec3 ng = cross(p2 - p0, p1 - p0);
+        if (lengthSquared(ng) == 0) return false;
+        coordinateSystem(normalize(ng), dpdu, dpdv);
+    }
+    vec3 pHit = b[0] * p0 + b[1] * p1 + b[2] * p2;
+    // SurfaceInteraction(pHit, uvHit, -ray.d, dpdu, dpdv) (Utils/Interaction.cpp:9-11)
+    isect.p = pHit;
+    isect.wo = normalize(-ray.d);
+    isect.n = normalize(cross(dpdu, dpdv));
+    isect.dpdu = dpdu;
+    isect.dpdv = dpdv;
+    isect.n = normalize(cross(dp02, dp12));
+    if (!s.triN.empty() && (s.hasN.empty() || s.hasN[prim])) {
+        vec3 ns = b[0] * s.N(prim, 0) + b[1] * s.N(prim, 1) + b[2] * s.N(prim, 2);
+        if (lengthSquared(ns) > 0) ns = normalize(ns);
+        else ns = isect.n;
+        isect.n = ns;
+    }
+    isect.prim = prim;
+    isect.b[0] = b[0]; isect.b[1] = b[1]; isect.b[2] = b[2];
+    return true;
+}
+
+// HitableObject::hit(ray, isect) (Object/Hitable.cpp:21-30)
+bool primHit(const Scene &s, int prim, const Ray &ray, SurfaceInteraction &isect, Counters *cn) {
+    if (cn) ++cn->tri;
+    float t, b[3];
+    if (!triTest(s, prim, ray, t, b)) return false;
+    if (!triSurface(s, prim, ray, b, isect)) return false;
+    ray.tMax = t;
+    return true;
+}
+bool primHitAny(const Scene &s, int prim, const Ray &ray, Counters *cn) {
+    if (cn) ++cn->tri;
+    float t, b[3];
+    return triTest(s, prim, ray, t, b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// KD-tree traversal (Accelerators/KDTree.cpp:284-490)
+// ------------------------------------------------------------------------------------------------
+bool boundsHit(const Scene &s, const Ray &ray, float &hitt0, float &hitt1) {   // Utils/Math.h:572-601
+    float t0 = 0, t1 = ray.tMax;
+    for (int i = 0; i < 3; ++i) {
+        float invRayDir = 1 / ray.d[i];
+        float tNear = (s.bmin[i] - ray.o[i]) * invRayDir;
+        float tFar = (s.bmax[i] - ray.o[i]) * invRayDir;
+        if (tNear > tFar) std::swap(tNear, tFar);
+        tFar *= 1 + 2 * gammaErr(3);
+        t0 = tNear > t0 ? tNear : t0;
+        t1 = tFar < t1 ? tFar : t1;
+        if (t0 > t1) return false;
+    }
+    hitt0 = t0;
+    hitt1 = t1;
+    return true;
+}
+
+struct Todo { uint32_t node; float tMin, tMax; };
+inline float nodeSplit(const Scene &s, uint32_t n) { float f; std::memcpy(&f, &s.nodes[2 * n], 4); return f; }
+
+bool kdHitClosest(const Scene &s, const Ray &ray, SurfaceInteraction &isect, Counters *cn) {
+    if (cn) ++cn->rays;
+    float tMin, tMax;
+    if (!boundsHit(s, ray, tMin, tMax)) return false;
+    vec3 invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
+    Todo todo[64];
+    int todoPos = 0;
+    bool hit = false;
+    uint32_t node = 0;
+    for (;;) {
+        if (ray.tMax < tMin) break;
+        const uint32_t w1 = s.nodes[2 * node + 1];
+        if ((w1 & 3u) != 3u) {
+            if (cn) ++cn->interior;
+            const int axis = (int)(w1 & 3u);
+            const float split = nodeSplit(s, node);
+            float tPlane = (split - ray.o[axis]) * invDir[axis];
+            uint32_t first, second;
+            int belowFirst = (ray.o[axis] < split) || (ray.o[axis] == split && ray.d[axis] <= 0);
+            if (belowFirst) { first = node + 1; second = w1 >> 2; }
+            else { first = w1 >> 2; second = node + 1; }
+            if (tPlane > tMax || tPlane <= 0) node = first;
+            else if (tPlane < tMin) node = second;
+            else {
+                todo[todoPos].node = second;
+                todo[todoPos].tMin = tPlane;
+                todo[todoPos].tMax = tMax;
+                ++todoPos;
+                if (cn && (uint64_t)todoPos > cn->maxStack) cn->maxStack = todoPos;
+                node = first;
+                tMax = tPlane;
+            }
+        } else {
+            if (cn) ++cn->leaf;
+            const int n = (int)(w1 >> 2);
+            if (n == 1) {
+                if (primHit(s, (int)s.nodes[2 * node], ray, isect, cn)) hit = true;
+            } else {
+                const uint32_t off = s.nodes[2 * node];
+                for (int i = 0; i < n; ++i) {
+                    if (cn) ++cn->leafIdx;
+                    if (primHit(s, s.leafIdx[off + i], ray, isect, cn)) hit = true;
+                }
+            }
+            if (todoPos > 0) {
+                --todoPos;
+                node = todo[todoPos].node;
+                tMin = todo[todoPos].tMin;
+                tMax = todo[todoPos].tMax;
+            } else break;
+        }
+    }
+    return hit;
+}
+
+bool kdHitAny(const Scene &s, const Ray &ray, Counters *cn) {
+    if (cn) ++cn->rays;
+    float tMin, tMax;
+    if (!boundsHit(s, ray, tMin, tMax)) return false;
+    vec3 invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
+    Todo todo[64];
+    int todoPos = 0;
+    uint32_t node = 0;
+    for (;;) {
+        const uint32_t w1 = s.nodes[2 * node + 1];
+        if ((w1 & 3u) == 3u) {
+            if (cn) ++cn->leaf;
+            const int n = (int)(w1 >> 2);
+            if (n == 1) {
+                if (primHitAny(s, (int)s.nodes[2 * node], ray, cn)) return true;
+            } else {
+                const uint32_t off = s.nodes[2 * node];
+                for (int i = 0; i < n; ++i) {
+                    if (cn) ++cn->leafIdx;
+                    if (primHitAny(s, s.leafIdx[off + i], ray, cn)) return true;
+                }
+            }
+            if (todoPos > 0) {
+                --todoPos;
+                node = todo[todoPos].node;
+                tMin = todo[todoPos].tMin;
+                tMax = todo[todoPos].tMax;
+            } else break;
+        } else {
+            if (cn) ++cn->interior;
+            const int axis = (int)(w1 & 3u);
+            const float split = nodeSplit(s, node);
+            float tPlane = (split - ray.o[axis]) * invDir[axis];
+            uint32_t first, second;
+            int belowFirst = (ray.o[axis] < split) || (ray.o[axis] == split && ray.d[axis] <= 0);
+            if (belowFirst) { first = node + 1; second = w1 >> 2; }
+            else { first = w1 >> 2; second = node + 1; }
+            if (tPlane > tMax || tPlane <= 0) node = first;
+            else if (tPlane < tMin) node = second;
+            else {
+                todo[todoPos].node = second;
+                todo[todoPos].tMin = tPlane;
+                todo[todoPos].tMax = tMax;
+                ++todoPos;
+                node = first;
+                tMax = tPlane;
+            }
+        }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling warps (Render/Sampler.cpp:120-148, Sampler.h:71-89)
+// ------------------------------------------------------------------------------------------------
+void concentricSampleDisk(const float u[2], float out[2]) {
+    float ox = 2.f * u[0] - 1, oy = 2.f * u[1] - 1;
+    if (ox == 0 && oy == 0) { out[0] = 0; out[1] = 0; return; }
+    float theta, r;
+    if (std::fabs(ox) > std::fabs(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
+    else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
+    out[0] = r * std::cos(theta);
+    out[1] = r * std::sin(theta);
+}
+vec3 cosineSampleHemisphere(const float u[2]) {
+    float d[2];
+    concentricSampleDisk(u, d);
+    float z = std::sqrt(gmax((float)0, 1 - d[0] * d[0] - d[1] * d[1]));
+    return vec3(d[0], d[1], z);
+}
+inline float powerHeuristic(int nf, float fPdf, int ng, float gPdf) {
+    float f = nf * fPdf, g = ng * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BSDF (Render/BSDF.h, BSDF.cpp)
+// ------------------------------------------------------------------------------------------------
+enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
+enum BxKind { BX_LAMBERT, BX_SPEC_REFL_NOOP, BX_SPEC_REFL_DIELECTRIC, BX_SPEC_TRANS };
+
+float frDielectric(float cosThetaI, float etaI, float etaT) {
+    cosThetaI = cosThetaI < -1 ? -1.f : (cosThetaI > 1 ? 1.f : cosThetaI);
+    bool entering = cosThetaI > 0.f;
+    if (!entering) { std::swap(etaI, etaT); cosThetaI = std::fabs(cosThetaI); }
+    float sinThetaI = std::sqrt(gmax((float)0, 1 - cosThetaI * cosThetaI));
+    float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1) return 1;
+    float cosThetaT = std::sqrt(gmax((float)0, 1 - sinThetaT * sinThetaT));
+    float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+bool refract(const vec3 &wi, const vec3 &n, float eta, vec3 &wt) {   // Utils/Math.h:661-674
+    float cosThetaI = dot(n, wi);
+    float sin2ThetaI = gmax(float(0), float(1 - cosThetaI * cosThetaI));
+    float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    float cosThetaT = std::sqrt(1 - sin2ThetaT);
+    wt = eta * -wi + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+}
+
+struct BxDF {
+    BxKind kind;
+    int type;
+    Spectrum R;
+    float etaA = 1, etaB = 1;
+    bool matches(int t) const { return (type & t) == type; }
+    Spectrum f(const vec3 &, const vec3 &) const { return kind == BX_LAMBERT ? R * kInvPi : Spectrum(0.f); }
+    float pdf(const vec3 &wo, const vec3 &wi) const {
+        if (kind != BX_LAMBERT) return 0.f;
+        return (wo.z * wi.z > 0) ? std::fabs(wi.z) * kInvPi : 0;
+    }
+    Spectrum sample_f(const vec3 &wo, vec3 &wi, const float u[2], float &pdfOut) const {
+        switch (kind) {
+        case BX_LAMBERT: {
+            wi = cosineSampleHemisphere(u);
+            if (wo.z < 0) wi.z *= -1;
+            pdfOut = pdf(wo, wi);
+            return f(wo, wi);
+        }
+        case BX_SPEC_REFL_NOOP:
+        case BX_SPEC_REFL_DIELECTRIC: {
+            wi = vec3(-wo.x, -wo.y, wo.z);
+            pdfOut = 1;
+            Spectrum fr = kind == BX_SPEC_REFL_NOOP ? Spectrum(1.f) : Spectrum(frDielectric(wi.z, etaA, etaB));
+            return fr * R / std::fabs(wi.z);
+        }
+        case BX_SPEC_TRANS: {
+            bool entering = (wo.z) > 0;
+            float etaI = entering ? etaA : etaB;
+            float etaT = entering ? etaB : etaA;
+            if (!refract(wo, faceforward(vec3(0, 0, 1), wo), etaI / etaT, wi)) return Spectrum(0.f);
+            pdfOut = 1;
+            Spectrum ft = R * (Spectrum(1.f) - Spectrum(frDielectric(wi.z, etaA, etaB)));
+            ft *= (etaI * etaI) / (etaT * etaT);   // TransportMode::Radiance
+            return ft / std::fabs(wi.z);
+        }
+        }
+        return Spectrum(0.f);
+    }
+};
+
+struct BSDF {
+    float eta = 1;
+    vec3 ns, ss, ts;
+    int nBxDFs = 0;
+    BxDF bx[8];
+    void init(const SurfaceInteraction &si, float e) {
+        eta = e;
+        ns = si.n;
+        ss = normalize(si.dpdu);
+        ts = cross(ns, ss);
+        nBxDFs = 0;
+    }
+    int numComponents(int flags) const {
+        int n = 0;
+        for (int i = 0; i < nBxDFs; ++i) if (bx[i].matches(flags)) ++n;
+        return n;
+    }
+    vec3 worldToLocal(const vec3 &v) const { return vec3(dot(v, ss), dot(v, ts), dot(v, ns)); }
+    vec3 localToWorld(const vec3 &v) const {
+        return vec3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
+    }
+    Spectrum f(const vec3 &woW, const vec3 &wiW, int flags) const {
+        vec3 wi = worldToLocal(wiW), wo = worldToLocal(woW);
+        if (wo.z == 0) return Spectrum(0.f);
+        bool reflect = dot(wiW, ns) * dot(woW, ns) > 0;
+        Spectrum r(0.f);
+        for (int i = 0; i < nBxDFs; ++i)
+            if (bx[i].matches(flags) && ((reflect && (bx[i].type & BSDF_REFLECTION)) || (!reflect && (bx[i].type & BSDF_TRANSMISSION))))
+                r += bx[i].f(wo, wi);
+        return r;
+    }
+    float pdf(const vec3 &woW, const vec3 &wiW, int flags) const {
+        if (nBxDFs == 0) return 0.f;
+        vec3 wo = worldToLocal(woW), wi = worldToLocal(wiW);
+        if (wo.z == 0) return 0.;
+        float p = 0.f;
+        int matching = 0;
+        for (int i = 0; i < nBxDFs; ++i)
+            if (bx[i].matches(flags)) { ++matching; p += bx[i].pdf(wo, wi); }
+        return matching > 0 ? p / matching : 0.f;
+    }
+    // sampledType: the reference reads the caller's uninitialised variable before writing it
+    // (BSDF.cpp:50,82,90); this restatement always writes it (the BxDF's type, or 0 on failure).
+    Spectrum sample_f(const vec3 &woWorld, vec3 &wiWorld, const float u[2], float &pdfOut, int &sampledType, int type) const {
+        int matchingComps = numComponents(type);
+        if (matchingComps == 0) { pdfOut = 0; sampledType = 0; return Spectrum(0.f); }
+        int comp = std::min((int)std::floor(u[0] * matchingComps), matchingComps - 1);
+        const BxDF *bxdf = nullptr;
+        int count = comp;
+        for (int i = 0; i < nBxDFs; ++i)
+            if (bx[i].matches(type) && count-- == 0) { bxdf = &bx[i]; break; }
+        float uRemapped[2] = {gmin(u[0] * matchingComps - comp, kOneMinusEpsilon), u[1]};
+        vec3 wi, wo = worldToLocal(woWorld);
+        if (wo.z == 0) { sampledType = 0; return Spectrum(0.f); }   // pdf is left as the caller had it
+        pdfOut = 0;
+        sampledType = bxdf->type;
+        Spectrum fv = bxdf->sample_f(wo, wi, uRemapped, pdfOut);
+        if (pdfOut == 0) { sampledType = 0; return Spectrum(0.f); }
+        wiWorld = localToWorld(wi);
+        if (!(bxdf->type & BSDF_SPECULAR) && matchingComps > 1)
+            for (int i = 0; i < nBxDFs; ++i)
+                if (&bx[i] != bxdf && bx[i].matches(type)) pdfOut += bx[i].pdf(wo, wi);
+        if (matchingComps > 1) pdfOut /= matchingComps;
+        if (!(bxdf->type & BSDF_SPECULAR)) {
+            bool reflect = dot(wiWorld, ns) * dot(woWorld, ns) > 0;
+            fv = Spectrum(0.f);
+            for (int i = 0; i < nBxDFs; ++i)
+                if (bx[i].matches(type) && ((reflect && (bx[i].type & BSDF_REFLECTION)) || (!reflect && (bx[i].type & BSDF_TRANSMISSION))))
+                    fv += bx[i].f(wo, wi);
+        }
+        return fv;
+    }
+};
+
+// Material::computeScatteringFunctions
+void makeBSDF(const Scene &s, const SurfaceInteraction &si, BSDF &b) {
+    const rt_material &m = s.materials[s.materialId[si.prim]];
+    Spectrum R(m.rgb[0], m.rgb[1], m.rgb[2]);
+    if (m.type == RT_MAT_GLASS) {
+        b.init(si, m.eta);
+        if (!R.isBlack()) {
+            BxDF r; r.kind = BX_SPEC_REFL_DIELECTRIC; r.type = BSDF_REFLECTION | BSDF_SPECULAR; r.R = R; r.etaA = 1.f; r.etaB = m.eta;
+            b.bx[b.nBxDFs++] = r;
+            BxDF t; t.kind = BX_SPEC_TRANS; t.type = BSDF_TRANSMISSION | BSDF_SPECULAR; t.R = R; t.etaA = 1.f; t.etaB = m.eta;
+            b.bx[b.nBxDFs++] = t;
+        }
+        return;
+    }
+    b.init(si, 1);
+    if (R.isBlack()) return;
+    BxDF x;
+    x.R = R;
+    if (m.type == RT_MAT_LAMBERTIAN) { x.kind = BX_LAMBERT; x.type = BSDF_REFLECTION | BSDF_DIFFUSE; }
+    else { x.kind = BX_SPEC_REFL_NOOP; x.type = BSDF_REFLECTION | BSDF_SPECULAR; }
+    b.bx[b.nBxDFs++] = x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// area lights (Render/Light.h:105-108, Light.cpp:109-128; Shape/Shape.cpp:28-67)
+// ------------------------------------------------------------------------------------------------
+Spectrum lightL(const rt_light &l, const vec3 &n, const vec3 &w) {
+    return (l.two_sided || dot(n, w) > 0) ? Spectrum(l.emit[0], l.emit[1], l.emit[2]) : Spectrum(0.f);
+}
+Spectrum isectLe(const Scene &s, const SurfaceInteraction &isect, const vec3 &w) {   // Utils/Interaction.cpp:13-17
+    int lid = s.lightId[isect.prim];
+    return lid >= 0 ? lightL(s.lights[lid], isect.n, w) : Spectrum(0.f);
+}
+// ATriangleShape::sample(u, pdf) (TriangleShape.cpp:162-176)
+Interaction triSample(const Scene &s, int prim, float area, const float u[2], float &pdf) {
+    float su0 = std::sqrt(u[0]);
+    float b0 = 1 - su0, b1 = u[1] * su0;
+    vec3 p0 = s.P(prim, 0), p1 = s.P(prim, 1), p2 = s.P(prim, 2);
+    Interaction it;
+    it.p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+    it.n = normalize(cross(p1 - p0, p2 - p0));
+    pdf = 1 / area;
+    return it;
+}
+// Shape::sample(ref, u, pdf)
+Interaction shapeSample(const Scene &s, int prim, float area, const Interaction &ref, const float u[2], float &pdf) {
+    Interaction intr = triSample(s, prim, area, u, pdf);
+    vec3 wi = intr.p - ref.p;
+    if (dot(wi, wi) == 0) pdf = 0;
+    else {
+        wi = normalize(wi);
+        vec3 dd = ref.p - intr.p;
+        pdf *= dot(dd, dd) / absDot(intr.n, -wi);
+        if (std::isinf(pdf)) pdf = 0.f;
+    }
+    return intr;
+}
+// DiffuseAreaLight::sample_Li
+Spectrum lightSampleLi(const Scene &s, int lid, const Interaction &ref, const float u[2], vec3 &wi, float &pdf, Interaction &pShapeOut) {
+    const rt_light &l = s.lights[lid];
+    Interaction pShape = shapeSample(s, l.prim_id, s.lightArea[lid], ref, u, pdf);
+    if (pdf == 0 || lengthSquared(pShape.p - ref.p) == 0) { pdf = 0; return Spectrum(0.f); }
+    wi = normalize(pShape.p - ref.p);
+    pShapeOut = pShape;
+    return lightL(l, pShape.n, -wi);
+}
+// DiffuseAreaLight::pdf_Li -> Shape::pdf(ref, wi)
+float lightPdfLi(const Scene &s, int lid, const Interaction &ref, const vec3 &wi) {
+    const rt_light &l = s.lights[lid];
+    Ray ray = ref.spawnRay(wi);
+    SurfaceInteraction isectLight;
+    float t, b[3];
+    if (!triTest(s, l.prim_id, ray, t, b)) return 0;
+    if (!triSurface(s, l.prim_id, ray, b, isectLight)) return 0;
+    vec3 dd = ref.p - isectLight.p;
+    float pdf = dot(dd, dd) / (absDot(isectLight.n, -wi) * s.lightArea[lid]);
+    if (std::isinf(pdf)) pdf = 0.f;
+    return pdf;
+}
+bool unoccluded(const Scene &s, const Interaction &p0, const Interaction &p1, Counters *cn, uint64_t *nAny) {
+    if (nAny) ++*nAny;
+    return !kdHitAny(s, p0.spawnRayTo(p1), cn);
+}
+
+// Distribution1D::sampleDiscrete over the uniform light distribution
+int sampleLightDiscrete(const Scene &s, float u, float &pdf) {
+    int size = (int)s.cdf.size();
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (s.cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = first - 1;
+    offset = offset < 0 ? 0 : (offset > size - 2 ? size - 2 : offset);
+    pdf = (s.funcInt > 0) ? s.func[offset] / (s.funcInt * (int)s.func.size()) : 0;
+    return offset;
+}
+
+struct RayStats { uint64_t closest = 0, any = 0; };
+
+// ------------------------------------------------------------------------------------------------
+// integrators (Render/Render.cpp)
+// ------------------------------------------------------------------------------------------------
+Spectrum estimateDirect(const Scene &s, const SurfaceInteraction &isect, const BSDF &bsdf, const float uScattering[2], int lid,
+                        const float uLight[2], RayStats &rs, Counters *cn) {
+    const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+    Spectrum Ld(0.f);
+    vec3 wi;
+    float lightPdf = 0, scatteringPdf = 0;
+    Interaction pShape;
+    Spectrum Li = lightSampleLi(s, lid, isect, uLight, wi, lightPdf, pShape);
+    if (lightPdf > 0 && !Li.isBlack()) {
+        Spectrum f = bsdf.f(isect.wo, wi, bsdfFlags) * absDot(wi, isect.n);
+        scatteringPdf = bsdf.pdf(isect.wo, wi, bsdfFlags);
+        if (!f.isBlack()) {
+            if (!unoccluded(s, isect, pShape, cn, &rs.any)) Li = Spectrum(0.f);
+            if (!Li.isBlack()) {
+                float weight = powerHeuristic(1, lightPdf, 1, scatteringPdf);
+                Ld += f * Li * weight / lightPdf;
+            }
+        }
+    }
+    {   // area lights are never delta lights
+        int sampledType = 0;
+        Spectrum f = bsdf.sample_f(isect.wo, wi, uScattering, scatteringPdf, sampledType, bsdfFlags);
+        f *= absDot(wi, isect.n);
+        bool sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+        if (!f.isBlack() && scatteringPdf > 0) {
+            float weight = 1;
+            if (!sampledSpecular) {
+                lightPdf = lightPdfLi(s, lid, isect, wi);
+                if (lightPdf == 0) return Ld;
+                weight = powerHeuristic(1, scatteringPdf, 1, lightPdf);
+            }
+            SurfaceInteraction lightIsect;
+            Ray ray = isect.spawnRay(wi);
+            ++rs.closest;
+            bool found = kdHitClosest(s, ray, lightIsect, cn);
+            Spectrum Li2(0.f);
+            if (found) {
+                if (s.lightId[lightIsect.prim] == lid) Li2 = isectLe(s, lightIsect, -wi);
+            }
+            if (!Li2.isBlack()) Ld += f * Li2 * Spectrum(1.f) * weight / scatteringPdf;
+        }
+    }
+    return Ld;
+}
+
+Spectrum uniformSampleOneLight(const Scene &s, const SurfaceInteraction &isect, const BSDF &bsdf, Sampler &sampler, RayStats &rs, Counters *cn) {
+    int nLights = (int)s.lights.size();
+    if (nLights == 0) return Spectrum(0.f);
+    float lightPdf;
+    int idx = sampleLightDiscrete(s, sampler.get1D(), lightPdf);
+    if (lightPdf == 0) return Spectrum(0.f);
+    float uLight[2], uScattering[2];
+    sampler.get2D(uLight);
+    sampler.get2D(uScattering);
+    return estimateDirect(s, isect, bsdf, uScattering, idx, uLight, rs, cn) / lightPdf;
+}
+
+Spectrum pathLi(const Scene &s, const Ray &r, Sampler &sampler, int maxDepth, float rrThreshold, RayStats &rs, Counters *cn) {
+    Spectrum L(0.f), beta(1.f);
+    Ray ray(r);
+    bool specularBounce = false;
+    float etaScale = 1;
+    for (int bounces = 0;; ++bounces) {
+        SurfaceInteraction isect;
+        ++rs.closest;
+        bool hit = kdHitClosest(s, ray, isect, cn);
+        if (bounces == 0 || specularBounce) {
+            if (hit) L += beta * isectLe(s, isect, -ray.d);
+        }
+        if (!hit || bounces >= maxDepth) break;
+        BSDF bsdf;
+        makeBSDF(s, isect, bsdf);
+        if (bsdf.numComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+            Spectrum Ld = beta * uniformSampleOneLight(s, isect, bsdf, sampler, rs, cn);
+            L += Ld;
+        }
+        vec3 wo = -ray.d, wi;
+        float pdf = 0;
+        int flags = 0;
+        float u[2];
+        sampler.get2D(u);
+        Spectrum f = bsdf.sample_f(wo, wi, u, pdf, flags, BSDF_ALL);
+        if (f.isBlack() || pdf == 0.f) break;
+        beta *= f * absDot(wi, isect.n) / pdf;
+        specularBounce = (flags & BSDF_SPECULAR) != 0;
+        if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+            float eta = bsdf.eta;
+            etaScale *= (dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+        }
+        ray = isect.spawnRay(wi);
+        Spectrum rrBeta = beta * etaScale;
+        if (rrBeta.maxComponentValue() < rrThreshold && bounces > 3) {
+            float q = gmax((float).05f, 1 - rrBeta.maxComponentValue());
+            if (sampler.get1D() < q) break;
+            beta /= 1 - q;
+        }
+    }
+    return L;
+}
+
+Spectrum whittedLi(const Scene &s, const Ray &ray, Sampler &sampler, int maxDepth, int depth, RayStats &rs, Counters *cn) {
+    Spectrum L(0.f);
+    SurfaceInteraction isect;
+    ++rs.closest;
+    if (!kdHitClosest(s, ray, isect, cn)) return L;   // area lights contribute nothing through Light::Le(ray)
+    const vec3 n = isect.n;
+    vec3 wo = isect.wo;
+    BSDF bsdf;
+    makeBSDF(s, isect, bsdf);
+    L += isectLe(s, isect, wo);
+    for (int lid = 0; lid < (int)s.lights.size(); ++lid) {
+        vec3 wi;
+        float pdf;
+        float u[2];
+        sampler.get2D(u);
+        Interaction pShape;
+        Spectrum Li = lightSampleLi(s, lid, isect, u, wi, pdf, pShape);
+        if (Li.isBlack() || pdf == 0) continue;
+        Spectrum f = bsdf.f(wo, wi, BSDF_ALL);
+        if (!f.isBlack() && unoccluded(s, isect, pShape, cn, &rs.any)) L += f * Li * absDot(wi, n) / pdf;
+    }
+    if (depth + 1 < maxDepth) {
+        for (int pass = 0; pass < 2; ++pass) {   // specularReflect, then specularTransmit (Render.cpp:106-152)
+            int type = (pass == 0 ? BSDF_REFLECTION : BSDF_TRANSMISSION) | BSDF_SPECULAR;
+            vec3 wi;
+            float pdf = 0;
+            int sampledType = 0;
+            float u[2];
+            sampler.get2D(u);
+            Spectrum f = bsdf.sample_f(wo, wi, u, pdf, sampledType, type);
+            if (pdf > 0.f && !f.isBlack() && absDot(wi, n) != 0.f) {
+                Ray rd = isect.spawnRay(wi);
+                L += f * whittedLi(s, rd, sampler, maxDepth, depth + 1, rs, cn) * absDot(wi, n) / pdf;
+            }
+        }
+    }
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// camera + film (Camera/Camera.cpp:87-95, Utils/Transform.h:75-97, Object/Film.h:111-155)
+// ------------------------------------------------------------------------------------------------
+vec3 xfApply(const float m[16], const vec3 &p, float w) {
+    float r[4];
+    for (int k = 0; k < 4; ++k) r[k] = (m[0 * 4 + k] * p.x + m[1 * 4 + k] * p.y) + (m[2 * 4 + k] * p.z + m[3 * 4 + k] * w);
+    if (w == 0.f) return vec3(r[0], r[1], r[2]);
+    if (r[3] == 1) return vec3(r[0], r[1], r[2]);
+    return vec3(r[0], r[1], r[2]) / r[3];
+}
+Ray cameraRay(const Scene &s, float fx, float fy) {
+    vec3 pCamera = xfApply(s.r2c, vec3(fx, fy, 0), 1.0f);
+    Ray ray(vec3(0, 0, 0), normalize(pCamera));
+    vec3 o = xfApply(s.c2w, ray.o, 1.0f);
+    vec3 d = xfApply(s.c2w, ray.d, 0.0f);
+    return Ray(o, d, ray.tMax);
+}
+
+Spectrum sanitize(Spectrum L) {   // Render.cpp:72-83
+    if (L.hasNaNs()) L = Spectrum(0.f);
+    else if (L.luminance() < -1e-5) L = Spectrum(0.f);
+    else if (std::isinf(L.luminance())) L = Spectrum(0.f);
+    return L;
+}
+
+}  // namespace
+
+// ====================================================================================================
+// C interface
+// ====================================================================================================
+struct oracle_scene {
+    Scene s;
+    std::string err;
+};
+
+extern "C" {
+
+oracle_scene *oracle_create(const rt_scene_desc *d) {
+    if (!d || !d->nodes || !d->tri_p || !d->material_id || !d->light_id || !d->materials) return nullptr;
+    auto *o = new oracle_scene();
+    Scene &s = o->s;
+    s.nodes.assign(d->nodes, d->nodes + 2 * (size_t)d->n_nodes);
+    if (d->n_leaf_idx) s.leafIdx.assign(d->leaf_idx, d->leaf_idx + d->n_leaf_idx);
+    s.bmin = vec3(d->bounds[0], d->bounds[1], d->bounds[2]);
+    s.bmax = vec3(d->bounds[3], d->bounds[4], d->bounds[5]);
+    s.nPrims = d->n_prims;
+    s.triP.assign(d->tri_p, d->tri_p + 9 * (size_t)d->n_prims);
+    if (d->tri_n) s.triN.assign(d->tri_n, d->tri_n + 9 * (size_t)d->n_prims);
+    if (d->tri_has_n) s.hasN.assign(d->tri_has_n, d->tri_has_n + d->n_prims);
+    if (d->tri_uv) { s.triUV.assign(d->tri_uv, d->tri_uv + 6 * (size_t)d->n_prims); s.hasUV = true; }
+    s.materialId.assign(d->material_id, d->material_id + d->n_prims);
+    s.lightId.assign(d->light_id, d->light_id + d->n_prims);
+    s.materials.assign(d->materials, d->materials + d->n_materials);
+    if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
+    for (auto &l : s.lights) s.lightArea.push_back(triArea(s, l.prim_id));
+    // UniformLightDistribution + Distribution1D (Utils/LightDistrib.cpp:17-21, LightDistrib.h:14-33)
+    int n = (int)s.lights.size();
+    if (n > 0) {
+        s.func.assign(n, 1.0f);
+        s.cdf.assign(n + 1, 0.f);
+        for (int i = 1; i < n + 1; ++i) s.cdf[i] = s.cdf[i - 1] + s.func[i - 1] / n;
+        s.funcInt = s.cdf[n];
+        if (s.funcInt == 0) for (int i = 1; i < n + 1; ++i) s.cdf[i] = float(i) / float(n);
+        else for (int i = 1; i < n + 1; ++i) s.cdf[i] /= s.funcInt;
+    }
+    return o;
+}
+
+void oracle_destroy(oracle_scene *o) { delete o; }
+
+int oracle_set_camera(oracle_scene *o, const float r2c[16], const float c2w[16], int width, int height, const int sb[4]) {
+    if (!o || !r2c || !c2w || !sb) return -1;
+    std::memcpy(o->s.r2c, r2c, 64);
+    std::memcpy(o->s.c2w, c2w, 64);
+    o->s.width = width;
+    o->s.height = height;
+    std::memcpy(o->s.sb, sb, 16);
+    o->s.hasCamera = true;
+    return 0;
+}
+
+int oracle_trace_closest(const oracle_scene *o, uint64_t n, const float *oxyz, const float *dxyz, const float *tmax,
+                         int32_t *prim, float *t, float *bary, oracle_counters *counters) {
+    if (!o) return -1;
+    Counters cn;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray ray;
+        ray.o = vec3(oxyz[3 * i], oxyz[3 * i + 1], oxyz[3 * i + 2]);
+        ray.d = vec3(dxyz[3 * i], dxyz[3 * i + 1], dxyz[3 * i + 2]);
+        ray.tMax = tmax ? tmax[i] : kInfinity;
+        SurfaceInteraction isect;
+        bool hit = kdHitClosest(o->s, ray, isect, counters ? &cn : nullptr);
+        if (prim) prim[i] = hit ? isect.prim : -1;
+        if (t) t[i] = ray.tMax;
+        if (bary) for (int k = 0; k < 3; ++k) bary[3 * i + k] = hit ? isect.b[k] : 0.f;
+    }
+    if (counters) {
+        counters->n_interior = cn.interior; counters->n_leaf = cn.leaf; counters->n_leaf_idx = cn.leafIdx;
+        counters->n_tri_tests = cn.tri; counters->n_rays = cn.rays; counters->max_stack = cn.maxStack;
+    }
+    return 0;
+}
+
+int oracle_trace_any(const oracle_scene *o, uint64_t n, const float *oxyz, const float *dxyz, const float *tmax,
+                     uint8_t *occluded, oracle_counters *counters) {
+    if (!o) return -1;
+    Counters cn;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray ray;
+        ray.o = vec3(oxyz[3 * i], oxyz[3 * i + 1], oxyz[3 * i + 2]);
+        ray.d = vec3(dxyz[3 * i], dxyz[3 * i + 1], dxyz[3 * i + 2]);
+        ray.tMax = tmax ? tmax[i] : kInfinity;
+        occluded[i] = kdHitAny(o->s, ray, counters ? &cn : nullptr) ? 1 : 0;
+    }
+    if (counters) {
+        counters->n_interior = cn.interior; counters->n_leaf = cn.leaf; counters->n_leaf_idx = cn.leafIdx;
+        counters->n_tri_tests = cn.tri; counters->n_rays = cn.rays; counters->max_stack = cn.maxStack;
+    }
+    return 0;
+}
+
+// Surface reconstruction for a (prim, barycentrics, ray direction) triple: p, n (shading), dpdu.
+int oracle_surface(const oracle_scene *o, int prim, const float b[3], const float d[3], float p[3], float n[3], float dpdu[3]) {
+    if (!o || prim < 0 || (uint32_t)prim >= o->s.nPrims) return -1;
+    Ray ray;
+    ray.d = vec3(d[0], d[1], d[2]);
+    SurfaceInteraction si;
+    if (!triSurface(o->s, prim, ray, b, si)) return -2;
+    for (int k = 0; k < 3; ++k) { p[k] = si.p[k]; n[k] = si.n[k]; dpdu[k] = si.dpdu[k]; }
+    return 0;
+}
+
+// Camera::castingRay for film positions.
+int oracle_camera_rays(const oracle_scene *o, uint64_t n, const float *film_xy, float *oxyz, float *dxyz) {
+    if (!o || !o->s.hasCamera) return -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray r = cameraRay(o->s, film_xy[2 * i], film_xy[2 * i + 1]);
+        for (int k = 0; k < 3; ++k) { oxyz[3 * i + k] = r.o[k]; dxyz[3 * i + k] = r.d[k]; }
+    }
+    return 0;
+}
+
+// SamplerRenderer::render. Accumulates into rgb_sum (w*h*3) / weight_sum (w*h).
+int oracle_render(const oracle_scene *o, const rt_render_params *p, float *rgb_sum, float *weight_sum, int n_threads,
+                  oracle_render_stats *stats_out) {
+    if (!o || !p || !rgb_sum || !weight_sum || !o->s.hasCamera) return -1;
+    const Scene &s = o->s;
+    const int tileSize = 16;
+    const int ex = s.sb[2] - s.sb[0], ey = s.sb[3] - s.sb[1];
+    const int ntx = (ex + tileSize - 1) / tileSize, nty = (ey + tileSize - 1) / tileSize;
+    const int nTiles = ntx * nty;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    std::atomic<int> next(0);
+    std::mutex mergeMutex;
+    std::atomic<uint64_t> totClosest(0), totAny(0), totSamples(0), totDraws(0);
+    Counters totalCn;
+    auto t0 = std::chrono::steady_clock::now();
+
+    auto worker = [&]() {
+        RayStats rs;
+        Counters cn;
+        Counters *cnp = p->collect_stats ? &cn : nullptr;
+        uint64_t samples = 0, draws = 0;
+        std::vector<float> trgb, tw;
+        for (;;) {
+            int t = next.fetch_add(1);
+            if (t >= nTiles) break;
+            int tx = t % ntx, ty = t / ntx;
+            int x0 = s.sb[0] + tx * tileSize, x1 = std::min(x0 + tileSize, s.sb[2]);
+            int y0 = s.sb[1] + ty * tileSize, y1 = std::min(y0 + tileSize, s.sb[3]);
+            // tile film: the tile's pixels plus a one-pixel border (Film::getFilmTile for radius 0.5), clipped to the film
+            int fx0 = std::max(x0 - 1, 0), fy0 = std::max(y0 - 1, 0), fx1 = std::min(x1 + 1, s.width), fy1 = std::min(y1 + 1, s.height);
+            int fw = fx1 - fx0, fh = fy1 - fy0;
+            trgb.assign((size_t)fw * fh * 3, 0.f);
+            tw.assign((size_t)fw * fh, 0.f);
+            Sampler sampler;
+            if (p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM) sampler.rng.setSequence((uint64_t)t);
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    for (int si = p->spp_begin; si < p->spp_end; ++si) {
+                        if (p->rng_mode == RT_RNG_COUNTER) {
+                            uint64_t pix = (uint64_t)y * (uint64_t)s.width + (uint64_t)x;
+                            uint64_t seq = pix * (uint64_t)p->spp_total + (uint64_t)si;
+                            sampler.rng.setSequence(splitmix64(seq + p->seed * 0x9E3779B97F4A7C15ULL));
+                        }
+                        float u[2];
+                        sampler.get2D(u);
+                        float pfx = (float)x + u[0], pfy = (float)y + u[1];
+                        Ray ray = cameraRay(s, pfx, pfy);
+                        Spectrum L = p->integrator == RT_INTEGRATOR_PATH
+                                         ? pathLi(s, ray, sampler, p->max_depth, p->rr_threshold, rs, cnp)
+                                         : whittedLi(s, ray, sampler, p->max_depth, 0, rs, cnp);
+                        L = sanitize(L);
+                        // accumulate into the tile film (offset coordinates), clipped like FilmTile::addSample
+                        {
+                            float dx = pfx - 0.5f, dy = pfy - 0.5f;
+                            int ax0 = (int)std::ceil(dx - 0.5f), ay0 = (int)std::ceil(dy - 0.5f);
+                            int ax1 = (int)std::floor(dx + 0.5f) + 1, ay1 = (int)std::floor(dy + 0.5f) + 1;
+                            ax0 = std::max(ax0, fx0); ay0 = std::max(ay0, fy0);
+                            ax1 = std::min(ax1, fx1); ay1 = std::min(ay1, fy1);
+                            for (int yy = ay0; yy < ay1; ++yy)
+                                for (int xx = ax0; xx < ax1; ++xx) {
+                                    Spectrum c = L * 1.0f * 1.0f;
+                                    size_t k = (size_t)(yy - fy0) * fw + (xx - fx0);
+                                    trgb[3 * k] += c.c[0]; trgb[3 * k + 1] += c.c[1]; trgb[3 * k + 2] += c.c[2];
+                                    tw[k] += 1.0f;
+                                }
+                        }
+                        ++samples;
+                    }
+                }
+            draws += sampler.draws;
+            std::lock_guard<std::mutex> lock(mergeMutex);
+            for (int yy = 0; yy < fh; ++yy)
+                for (int xx = 0; xx < fw; ++xx) {
+                    size_t k = (size_t)yy * fw + xx, g = (size_t)(yy + fy0) * s.width + (xx + fx0);
+                    rgb_sum[3 * g] += trgb[3 * k]; rgb_sum[3 * g + 1] += trgb[3 * k + 1]; rgb_sum[3 * g + 2] += trgb[3 * k + 2];
+                    weight_sum[g] += tw[k];
+                }
+        }
+        totClosest += rs.closest; totAny += rs.any; totSamples += samples; totDraws += draws;
+        if (cnp) {
+            std::lock_guard<std::mutex> lock(mergeMutex);
+            totalCn.interior += cn.interior; totalCn.leaf += cn.leaf; totalCn.leafIdx += cn.leafIdx; totalCn.tri += cn.tri;
+            totalCn.rays += cn.rays;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_threads; ++i) th.emplace_back(worker);
+    worker();
+    for (auto &x : th) x.join();
+    auto t1 = std::chrono::steady_clock::now();
+    if (stats_out) {
+        stats_out->rays_closest = totClosest; stats_out->rays_any = totAny; stats_out->camera_samples = totSamples;
+        stats_out->rng_draws = totDraws;
+        stats_out->seconds = std::chrono::duration<double>(t1 - t0).count();
+        stats_out->threads = n_threads;
+        stats_out->n_interior = totalCn.interior; stats_out->n_leaf = totalCn.leaf; stats_out->n_leaf_idx = totalCn.leafIdx;
+        stats_out->n_tri_tests = totalCn.tri; stats_out->counted_rays = totalCn.rays;
+    }
+    return 0;
+}
+
+// PCG32 stream check: first n floats of sequence `seq`.
+void oracle_rng_floats(uint64_t seq, int n, float *out) {
+    Rng r;
+    r.setSequence(seq);
+    for (int i = 0; i < n; ++i) out[i] = r.uniformFloat();
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+/* C interface of the CPU oracle (test infrastructure; see oracle.cpp). */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+#include <stdint.h>
+#include "../include/raytracing_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_scene oracle_scene;
+
+typedef struct oracle_counters {
+    uint64_t n_interior, n_leaf, n_leaf_idx, n_tri_tests, n_rays, max_stack;
+} oracle_counters;
+
+typedef struct oracle_render_stats {
+    uint64_t rays_closest, rays_any, camera_samples, rng_draws;
+    double seconds;
+    int32_t threads;
+    uint64_t n_interior, n_leaf, n_leaf_idx, n_tri_tests, counted_rays;
+} oracle_render_stats;
+
+oracle_scene *oracle_create(const rt_scene_desc *d);
+void oracle_destroy(oracle_scene *o);
+int oracle_set_camera(oracle_scene *o, const float r2c[16], const float c2w[16], int width, int height, const int sb[4]);
+int oracle_trace_closest(const oracle_scene *o, uint64_t n, const float *oxyz, const float *dxyz, const float *tmax,
+                         int32_t *prim, float *t, float *bary, oracle_counters *counters);
+int oracle_trace_any(const oracle_scene *o, uint64_t n, const float *oxyz, const float *dxyz, const float *tmax,
+                     uint8_t *occluded, oracle_counters *counters);
+int oracle_surface(const oracle_scene *o, int prim, const float b[3], const float d[3], float p[3], float n[3], float dpdu[3]);
+int oracle_camera_rays(const oracle_scene *o, uint64_t n, const float *film_xy, float *oxyz, float *dxyz);
+int oracle_render(const oracle_scene *o, const rt_render_params *p, float *rgb_sum, float *weight_sum, int n_threads,
+                  oracle_render_stats *stats_out);
+void oracle_rng_floats(uint64_t seq, int n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
