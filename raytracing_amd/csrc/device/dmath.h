@@ -6,26 +6,27 @@
 #include <stdint.h>
 
 #define RT_DEV __device__ __forceinline__
+#define RT_HD __host__ __device__ __forceinline__
 
 struct f3 {
     float x, y, z;
 };
-RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-RT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-RT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-RT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
-RT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-RT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
-RT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
-RT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
-RT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-RT_DEV float absdot3(f3 a, f3 b) { return fabsf(dot3(a, b)); }
-RT_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-RT_DEV f3 normalize3(f3 a) { return a * (1.0f / sqrtf(dot3(a, a))); }
-RT_DEV float gmin(float x, float y) { return (y < x) ? y : x; }   // glm::min: NaN handling differs from fminf
-RT_DEV float gmax(float x, float y) { return (x < y) ? y : x; }   // glm::max
-RT_DEV float comp3(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
-RT_DEV bool black3(f3 c) { return c.x == 0.f && c.y == 0.f && c.z == 0.f; }
+RT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_HD f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+RT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RT_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD float absdot3(f3 a, f3 b) { return fabsf(dot3(a, b)); }
+RT_HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+RT_HD f3 normalize3(f3 a) { return a * (1.0f / sqrtf(dot3(a, a))); }
+RT_HD float gmin(float x, float y) { return (y < x) ? y : x; }   // glm::min: NaN handling differs from fminf
+RT_HD float gmax(float x, float y) { return (x < y) ? y : x; }   // glm::max
+RT_HD float comp3(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+RT_HD bool black3(f3 c) { return c.x == 0.f && c.y == 0.f && c.z == 0.f; }
 
 #define RT_PI 3.14159265358979323846f
 #define RT_INV_PI 0.31830988618379067154f
@@ -73,7 +74,7 @@ RT_DEV uint64_t counter_sequence(uint64_t pix, uint32_t spp_total, uint32_t s, u
 // produces, reference src/core/Render/Sampler.cpp:120-142), evaluated in double and rounded once to
 // float: agrees with a correctly rounded sinf/cosf except when the exact value lies within ~1e-9 ulp
 // of a rounding boundary.
-RT_DEV void sincos_disk(float theta, float &s, float &c) {
+RT_HD void sincos_disk(float theta, float &s, float &c) {
     double t = (double)theta;
     bool upper = theta > RT_PI_OVER_4;
     double r = upper ? t - 1.5707963267948966192313216916398 : t;   // |r| <= pi/4 (+ float slack)

@@ -1,0 +1,278 @@
+// KD-tree traversal and the watertight ray/triangle test on the device.
+//
+// One lane owns one ray and performs exactly the sequence of node visits, primitive tests and float
+// operations of the reference's KdTree::hit pair (reference src/core/Accelerators/KDTree.cpp:284-490,
+// root clip src/core/Utils/Math.h:572-601) and ATriangleShape::hit pair
+// (src/core/Shape/TriangleShape.cpp:178-385): same comparisons (so NaNs from 0*inf fall through the
+// same branches), same visit order (ties in t let the last tested primitive win), no mailboxing.
+// What changes is the schedule: lanes descend interior nodes together and meet at leaves, the
+// per-ray shear constants are computed once per ray instead of once per triangle, and the todo stack
+// lives in LDS (first STACK_LDS entries) with a private-memory tail.
+#pragma once
+#include "dmath.h"
+
+#define RT_BLOCK 256
+#define RT_STACK_LDS 8        // todo entries per lane kept in LDS
+#define RT_STACK_PRIV 56      // remaining entries (the reference's todo[64])
+
+struct DevMaterial {
+    float r, g, b, eta;
+    int type, pad0, pad1, pad2;
+};
+struct DevLight {
+    float er, eg, eb;
+    int twoSided;
+    int prim;
+    float area;
+    float pad0, pad1;
+};
+
+// Device scene: separate tables per access pattern. Records are 16-byte multiples so a lane's gather
+// is one or a few dwordx4 loads.
+//   nodes     uint2  per node   {split | onePrim | indexOffset, axis/leaf flag | child or count << 2}
+//   leafIdx   int    per leaf reference
+//   triHot    float4 x3 per primitive: p0, p1, p2 (w of p0 = 1.0f when the triangle is degenerate for
+//             the closest-hit flavour, TriangleShape.cpp:414-421)
+//   triShade  float4 x5 per primitive: {n0, ss.x} {n1, ss.y} {n2, ss.z} {geometric n, hasNormals}
+//             {materialId, lightId, -, -} — read by shading only
+struct DevScene {
+    const uint2 *nodes;
+    const int *leafIdx;
+    const float4 *triHot;
+    const float4 *triShade;
+    const DevMaterial *mats;
+    const DevLight *lights;
+    const float *lightCdf;    // nLights + 1
+    const float *lightFunc;   // nLights
+    float bmin[3], bmax[3];
+    uint32_t nNodes, nLeafIdx, nPrims, nMats, nLights;
+    float lightFuncInt;
+    uint32_t ldsSceneBytes;   // nodes + leafIdx + triHot, each padded to 16 B; 0 = does not fit in LDS
+};
+
+struct RayCtx {
+    f3 o, d, invDir;
+    f3 op;             // origin with the triangle test's axis permutation applied
+    int kz;
+    float Sx, Sy, Sz;
+};
+
+struct TravCounters {
+    uint32_t interior, leaf, leafIdx, tri;
+};
+
+RT_DEV f3 perm3(f3 v, int kz) {
+    // kz = 0: (y, z, x); kz = 1: (z, x, y); kz = 2: (x, y, z)   (kx = kz+1 mod 3, ky = kx+1 mod 3)
+    return mk3(kz == 0 ? v.y : (kz == 1 ? v.z : v.x), kz == 0 ? v.z : (kz == 1 ? v.x : v.y), kz == 0 ? v.x : (kz == 1 ? v.y : v.z));
+}
+
+RT_DEV void ray_setup(RayCtx &r, f3 o, f3 d) {
+    r.o = o;
+    r.d = d;
+    r.invDir = mk3(1 / d.x, 1 / d.y, 1 / d.z);
+    f3 a = mk3(fabsf(d.x), fabsf(d.y), fabsf(d.z));
+    r.kz = (a.x > a.y) ? ((a.x > a.z) ? 0 : 2) : ((a.y > a.z) ? 1 : 2);
+    f3 dp = perm3(d, r.kz);
+    r.Sx = -dp.x / dp.z;
+    r.Sy = -dp.y / dp.z;
+    r.Sz = 1.f / dp.z;
+    r.op = perm3(o, r.kz);
+}
+
+// Root slab clip (BBox3::hit).
+RT_DEV bool bounds_clip(const DevScene &sc, const RayCtx &r, float rayTMax, float &hitt0, float &hitt1) {
+    float t0 = 0, t1 = rayTMax;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float inv = comp3(r.invDir, i);
+        const float oi = comp3(r.o, i);
+        float tNear = (sc.bmin[i] - oi) * inv;
+        float tFar = (sc.bmax[i] - oi) * inv;
+        if (tNear > tFar) { float tmp = tNear; tNear = tFar; tFar = tmp; }
+        tFar *= 1 + 2 * gamma_err(3);
+        t0 = tNear > t0 ? tNear : t0;
+        t1 = tFar < t1 ? tFar : t1;
+        if (t0 > t1) return false;
+    }
+    hitt0 = t0;
+    hitt1 = t1;
+    return true;
+}
+
+// Ray/triangle test. rayTMax is the ray's current m_tMax.
+RT_DEV bool tri_test(const RayCtx &r, f3 p0, f3 p1, f3 p2, float rayTMax, float &tOut, float &b0o, float &b1o, float &b2o) {
+    f3 p0t = perm3(p0, r.kz) - r.op;
+    f3 p1t = perm3(p1, r.kz) - r.op;
+    f3 p2t = perm3(p2, r.kz) - r.op;
+    p0t.x += r.Sx * p0t.z; p0t.y += r.Sy * p0t.z;
+    p1t.x += r.Sx * p1t.z; p1t.y += r.Sy * p1t.z;
+    p2t.x += r.Sx * p2t.z; p2t.y += r.Sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double p2txp1ty = (double)p2t.x * (double)p1t.y;
+        double p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y;
+        double p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y;
+        double p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0t.z *= r.Sz;
+    p1t.z *= r.Sz;
+    p2t.z *= r.Sz;
+    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < rayTMax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > rayTMax * det)) return false;
+    float invDet = 1 / det;
+    float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    float t = tScaled * invDet;
+    float maxZt = gmax(fabsf(p0t.z), gmax(fabsf(p1t.z), fabsf(p2t.z)));
+    float deltaZ = gamma_err(3) * maxZt;
+    float maxXt = gmax(fabsf(p0t.x), gmax(fabsf(p1t.x), fabsf(p2t.x)));
+    float maxYt = gmax(fabsf(p0t.y), gmax(fabsf(p1t.y), fabsf(p2t.y)));
+    float deltaX = gamma_err(5) * (maxXt + maxZt);
+    float deltaY = gamma_err(5) * (maxYt + maxZt);
+    float deltaE = 2 * (gamma_err(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = gmax(fabsf(e0), gmax(fabsf(e1), fabsf(e2)));
+    float deltaT = 3 * (gamma_err(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
+    if (t <= deltaT) return false;
+    tOut = t;
+    b0o = b0; b1o = b1; b2o = b2;
+    return true;
+}
+
+struct HitRec {
+    int prim;
+    float t, b0, b1, b2;
+};
+
+// Pointers to the three traversal tables, either in HBM or staged in LDS.
+struct SceneTables {
+    const uint2 *nodes;
+    const int *leafIdx;
+    const float4 *triHot;
+};
+
+// Stack access: entry e of lane `tid` lives at stk[(e * 3 + k) * RT_BLOCK + tid] so that lanes at the
+// same depth hit consecutive banks.
+struct TodoStack {
+    uint32_t *lds;
+    uint32_t tid;
+    uint32_t privNode[RT_STACK_PRIV];
+    float privTMin[RT_STACK_PRIV], privTMax[RT_STACK_PRIV];
+};
+
+template <bool CLOSEST, bool STATS>
+RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsStack, uint32_t tid, const RayCtx &r, float rayTMaxIn,
+                     HitRec &hit, TravCounters &cn) {
+    float tMin, tMax;
+    float rayTMax = rayTMaxIn;
+    hit.prim = -1;
+    hit.t = rayTMaxIn;
+    hit.b0 = hit.b1 = hit.b2 = 0.f;
+    if (!bounds_clip(sc, r, rayTMax, tMin, tMax)) return false;
+
+    uint32_t privNode[RT_STACK_PRIV];
+    float privTMin[RT_STACK_PRIV], privTMax[RT_STACK_PRIV];
+    int sp = 0;
+    uint32_t node = 0;
+    bool found = false;
+    for (;;) {
+        if (CLOSEST && rayTMax < tMin) break;
+        uint2 nd = tb.nodes[node];
+        while ((nd.y & 3u) != 3u) {
+            if (STATS) ++cn.interior;
+            const int axis = (int)(nd.y & 3u);
+            const float split = __uint_as_float(nd.x);
+            const float oa = comp3(r.o, axis), da = comp3(r.d, axis), ia = comp3(r.invDir, axis);
+            const float tPlane = (split - oa) * ia;
+            const bool belowFirst = (oa < split) || (oa == split && da <= 0);
+            const uint32_t above = nd.y >> 2;
+            const uint32_t first = belowFirst ? node + 1 : above;
+            const uint32_t second = belowFirst ? above : node + 1;
+            if (tPlane > tMax || tPlane <= 0) {
+                node = first;
+            } else if (tPlane < tMin) {
+                node = second;
+            } else {
+                if (sp < RT_STACK_LDS) {
+                    ldsStack[(sp * 3 + 0) * RT_BLOCK + tid] = second;
+                    ldsStack[(sp * 3 + 1) * RT_BLOCK + tid] = __float_as_uint(tPlane);
+                    ldsStack[(sp * 3 + 2) * RT_BLOCK + tid] = __float_as_uint(tMax);
+                } else {
+                    const int q = sp - RT_STACK_LDS;
+                    privNode[q] = second;
+                    privTMin[q] = tPlane;
+                    privTMax[q] = tMax;
+                }
+                ++sp;
+                node = first;
+                tMax = tPlane;
+            }
+            nd = tb.nodes[node];
+        }
+        // leaf
+        if (STATS) ++cn.leaf;
+        const int n = (int)(nd.y >> 2);
+        for (int i = 0; i < n; ++i) {
+            int prim;
+            if (n == 1) prim = (int)nd.x;
+            else {
+                prim = tb.leafIdx[nd.x + i];
+                if (STATS) ++cn.leafIdx;
+            }
+            if (STATS) ++cn.tri;
+            const float4 q0 = tb.triHot[3 * prim + 0];
+            const float4 q1 = tb.triHot[3 * prim + 1];
+            const float4 q2 = tb.triHot[3 * prim + 2];
+            float t, b0, b1, b2;
+            if (tri_test(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2)) {
+                if (!CLOSEST) { hit.prim = prim; return true; }
+                if (q0.w == 0.f) {   // not degenerate
+                    rayTMax = t;
+                    hit.prim = prim;
+                    hit.t = t;
+                    hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+                    found = true;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        if (sp < RT_STACK_LDS) {
+            node = ldsStack[(sp * 3 + 0) * RT_BLOCK + tid];
+            tMin = __uint_as_float(ldsStack[(sp * 3 + 1) * RT_BLOCK + tid]);
+            tMax = __uint_as_float(ldsStack[(sp * 3 + 2) * RT_BLOCK + tid]);
+        } else {
+            const int q = sp - RT_STACK_LDS;
+            node = privNode[q];
+            tMin = privTMin[q];
+            tMax = privTMax[q];
+        }
+    }
+    return found;
+}
+
+// Cooperative copy of the traversal tables into LDS. `smem` must hold sc.ldsSceneBytes bytes, 16-B aligned.
+RT_DEV void stage_scene_lds(const DevScene &sc, uint4 *smem, SceneTables &tb) {
+    const uint32_t nodeVec = (sc.nNodes * 8 + 15) / 16;
+    const uint32_t idxVec = (sc.nLeafIdx * 4 + 15) / 16;
+    const uint32_t triVec = sc.nPrims * 3;
+    const uint4 *gn = reinterpret_cast<const uint4 *>(sc.nodes);
+    const uint4 *gi = reinterpret_cast<const uint4 *>(sc.leafIdx);
+    const uint4 *gt = reinterpret_cast<const uint4 *>(sc.triHot);
+    for (uint32_t i = threadIdx.x; i < nodeVec; i += blockDim.x) smem[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < idxVec; i += blockDim.x) smem[nodeVec + i] = gi[i];
+    for (uint32_t i = threadIdx.x; i < triVec; i += blockDim.x) smem[nodeVec + idxVec + i] = gt[i];
+    tb.nodes = reinterpret_cast<const uint2 *>(smem);
+    tb.leafIdx = reinterpret_cast<const int *>(smem + nodeVec);
+    tb.triHot = reinterpret_cast<const float4 *>(smem + nodeVec + idxVec);
+    __syncthreads();
+}

@@ -1,0 +1,732 @@
+// HIP kernels of the hot path for gfx950: batch closest/any-hit tracing, the wavefront path tracer
+// (raygen -> [extend -> shade -> shadow -> probe] per bounce -> film) and the Whitted integrator.
+#pragma once
+#include "dshade.h"
+
+// ---------------------------------------------------------------------------------------------------
+// device-side counters (one array per context)
+// ---------------------------------------------------------------------------------------------------
+enum {
+    ST_RAYS_CLOSEST = 0, ST_RAYS_ANY, ST_CAMERA_SAMPLES, ST_INTERIOR, ST_LEAF, ST_LEAFIDX, ST_TRI, ST_COUNTED_RAYS,
+    ST_EXTEND_RAYS, ST_COUNT
+};
+
+struct CameraDev {
+    float r2c[16], c2w[16];
+    int width, height;
+    int sb[4];   // sample bounds x0,y0,x1,y1
+};
+
+RT_DEV f3 xf_apply(const float *m, f3 p, float w) {   // Transform::operator()(Vec3, w), Utils/Transform.h:75-88
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (m[0 * 4 + k] * p.x + m[1 * 4 + k] * p.y) + (m[2 * 4 + k] * p.z + m[3 * 4 + k] * w);
+    if (w == 0.f) return mk3(r[0], r[1], r[2]);
+    if (r[3] == 1) return mk3(r[0], r[1], r[2]);
+    return mk3(r[0], r[1], r[2]) / r[3];
+}
+// APerspectiveCamera::castingRay (Camera/Camera.cpp:87-95): three normalisations, as the reference's Ray constructor does.
+RT_DEV void camera_ray(const CameraDev &cam, float fx, float fy, f3 &o, f3 &d) {
+    const f3 pCamera = xf_apply(cam.r2c, mk3(fx, fy, 0.f), 1.0f);
+    const f3 dir = normalize3(normalize3(pCamera));
+    o = xf_apply(cam.c2w, mk3(0.f, 0.f, 0.f), 1.0f);
+    d = normalize3(xf_apply(cam.c2w, dir, 0.0f));
+}
+
+RT_DEV void flush_counters(unsigned long long *stats, const TravCounters &cn, uint32_t rays) {
+    atomicAdd(&stats[ST_INTERIOR], (unsigned long long)cn.interior);
+    atomicAdd(&stats[ST_LEAF], (unsigned long long)cn.leaf);
+    atomicAdd(&stats[ST_LEAFIDX], (unsigned long long)cn.leafIdx);
+    atomicAdd(&stats[ST_TRI], (unsigned long long)cn.tri);
+    atomicAdd(&stats[ST_COUNTED_RAYS], (unsigned long long)rays);
+}
+
+// Dynamic LDS layout of every tracing kernel: [todo stack: RT_STACK_LDS*3*RT_BLOCK dwords][scene tables]
+#define RT_STACK_LDS_BYTES (RT_STACK_LDS * 3 * RT_BLOCK * 4)
+
+template <bool LDS_SCENE>
+RT_DEV void tables_setup(const DevScene &sc, uint4 *smem, SceneTables &tb) {
+    if (LDS_SCENE) {
+        stage_scene_lds(sc, smem + RT_STACK_LDS_BYTES / 16, tb);
+    } else {
+        tb.nodes = sc.nodes;
+        tb.leafIdx = sc.leafIdx;
+        tb.triHot = sc.triHot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batch tracing (rt_trace_closest / rt_trace_any)
+// ---------------------------------------------------------------------------------------------------
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
+                                                            const float *__restrict__ tmax, int *__restrict__ prim, float *__restrict__ tOut,
+                                                            float *__restrict__ bary, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    TravCounters cn = {0, 0, 0, 0};
+    uint32_t myRays = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RT_BLOCK) {
+        RayCtx r;
+        ray_setup(r, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+        HitRec h;
+        kd_trace<true, STATS>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
+        if (prim) prim[i] = h.prim;
+        if (tOut) tOut[i] = h.t;
+        if (bary) { bary[3 * i] = h.b0; bary[3 * i + 1] = h.b1; bary[3 * i + 2] = h.b2; }
+        ++myRays;
+    }
+    if (STATS) flush_counters(stats, cn, myRays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+}
+
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
+                                                        const float *__restrict__ tmax, uint8_t *__restrict__ occluded, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    TravCounters cn = {0, 0, 0, 0};
+    uint32_t myRays = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RT_BLOCK) {
+        RayCtx r;
+        ray_setup(r, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+        HitRec h;
+        const bool hit = kd_trace<false, STATS>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
+        occluded[i] = hit ? 1 : 0;
+        ++myRays;
+    }
+    if (STATS) flush_counters(stats, cn, myRays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wavefront path tracer
+// ---------------------------------------------------------------------------------------------------
+// Queue slot layouts (all float4, indexed by queue slot so a wave reads contiguous memory):
+//   ray   A = {o.xyz, d.x}   B = {d.y, d.z, bits(pathId | specularBounce << 31), -}
+//   hit     = {bits(prim), b0, b1, b2}
+//   shadow A = {o.xyz, d.x}  B = {d.y, d.z, bits(pathId), c.r}  C = {c.g, c.b, -, -}
+//   probe   = 6 float4: {p, hasShadow} {shadowDir, pathId} {A, light} {wi, weight} {f|cos|, pdf} {beta, selPdf}
+// Per-path state (indexed by pathId = localSample * nPix + pixel):
+//   L = {rgb, etaScale}   beta = {rgb, -}   rng = PCG32 state (the increment is recomputed from the path id)
+struct PathBuffers {
+    float4 *rayA[2], *rayB[2];
+    float4 *hit;
+    float4 *L, *beta;
+    uint2 *rng;
+    float4 *shA, *shB, *shC;
+    float4 *probe;
+    uint32_t *counts;   // [(maxDepth + 2)][4]: 0 = rays entering bounce b, 1 = shadow entries, 2 = probe entries
+};
+
+struct PassInfo {
+    uint32_t nPix;         // pixels in the sample bounds
+    uint32_t sbW;          // sample-bounds width
+    uint32_t sppPass;      // samples per pixel in this pass
+    uint32_t sppBase;      // global index of local sample 0
+    uint32_t sppTotal;
+    uint64_t seed;
+    int maxDepth;
+    float rrThreshold;
+};
+
+RT_DEV uint64_t path_sequence(const CameraDev &cam, const PassInfo &ps, uint32_t pathId, int &px, int &py, uint32_t &sLocal) {
+    sLocal = pathId / ps.nPix;
+    const uint32_t pi = pathId - sLocal * ps.nPix;
+    const uint32_t ly = pi / ps.sbW, lx = pi - ly * ps.sbW;
+    px = cam.sb[0] + (int)lx;
+    py = cam.sb[1] + (int)ly;
+    const uint64_t pix = (uint64_t)py * (uint64_t)cam.width + (uint64_t)px;
+    return counter_sequence(pix, ps.sppTotal, ps.sppBase + sLocal, ps.seed);
+}
+
+// Wave-aggregated append: returns this lane's slot when `want`, one atomic per wave.
+RT_DEV uint32_t wave_append(uint32_t *counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0;
+    const uint32_t lane = __lane_id();
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    return base + rank;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(CameraDev cam, PassInfo ps, PathBuffers pb, unsigned long long *stats) {
+    const uint32_t n = ps.nPix * ps.sppPass;
+    for (uint32_t id = blockIdx.x * RT_BLOCK + threadIdx.x; id < n; id += gridDim.x * RT_BLOCK) {
+        int px, py;
+        uint32_t sLocal;
+        Pcg rng;
+        pcg_set_sequence(rng, path_sequence(cam, ps, id, px, py, sLocal));
+        const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+        f3 o, d;
+        camera_ray(cam, (float)px + u0, (float)py + u1, o, d);
+        pb.rayA[0][id] = make_float4(o.x, o.y, o.z, d.x);
+        pb.rayB[0][id] = make_float4(d.y, d.z, __uint_as_float(id), 0.f);
+        pb.L[id] = make_float4(0.f, 0.f, 0.f, 1.f);
+        pb.beta[id] = make_float4(1.f, 1.f, 1.f, 0.f);
+        pb.rng[id] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        pb.counts[0] = n;
+        atomicAdd(&stats[ST_CAMERA_SAMPLES], (unsigned long long)n);
+    }
+}
+
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
+                                                     float4 *__restrict__ hit, const uint32_t *__restrict__ count, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    const uint32_t n = *count;
+    if (blockIdx.x * RT_BLOCK >= n) return;   // whole block idle: skip the LDS staging
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    TravCounters cn = {0, 0, 0, 0};
+    uint32_t myRays = 0;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const float4 a = rayA[i], b = rayB[i];
+        RayCtx r;
+        ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+        HitRec h;
+        kd_trace<true, STATS>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+        hit[i] = make_float4(__int_as_float(h.prim), h.b0, h.b1, h.b2);
+        ++myRays;
+    }
+    if (STATS) flush_counters(stats, cn, myRays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+        atomicAdd(&stats[ST_EXTEND_RAYS], (unsigned long long)n);
+    }
+}
+
+// One bounce of PathRenderer::Li (Render/Render.cpp:363-445) for every live path, after its closest hit
+// is known: emission, light sampling with MIS (uniformSampleOneLight / estimateDirect, :189-312), BSDF
+// sampling, Russian roulette. Visibility is resolved by k_shadow / k_probe afterwards.
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, CameraDev cam, PassInfo ps, PathBuffers pb, int bounce) {
+    const int cur = bounce & 1, nxt = cur ^ 1;
+    const uint32_t n = pb.counts[bounce * 4 + 0];
+    uint32_t *cntNext = &pb.counts[(bounce + 1) * 4 + 0];
+    uint32_t *cntShadow = &pb.counts[bounce * 4 + 1];
+    uint32_t *cntProbe = &pb.counts[bounce * 4 + 2];
+    const uint32_t nRound = (n + 63u) & ~63u;   // whole waves enter the loop so ballots see every lane
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < nRound; i += gridDim.x * RT_BLOCK) {
+        bool alive = i < n;
+        bool wantShadow = false, wantProbe = false;
+        float4 sA, sB, sC;          // shadow entry
+        float4 pr[6];               // probe entry
+        float4 nA, nB;              // next ray
+        sA = sB = sC = nA = nB = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (alive) {
+            const float4 ra = pb.rayA[cur][i], rb = pb.rayB[cur][i];
+            const float4 hr = pb.hit[i];
+            const uint32_t idBits = __float_as_uint(rb.z);
+            const uint32_t pathId = idBits & 0x7fffffffu;
+            const bool specularBounce = (idBits >> 31) != 0;
+            const f3 rd = mk3(ra.w, rb.x, rb.y);
+            const int prim = __float_as_int(hr.x);
+            alive = false;   // set again when the path continues
+            if (prim >= 0) {
+                Surf sf;
+                surface_at(sc, prim, hr.y, hr.z, hr.w, sf);
+                float4 L4 = pb.L[pathId];
+                float4 beta4 = pb.beta[pathId];
+                f3 beta = mk3(beta4.x, beta4.y, beta4.z);
+                float etaScale = L4.w;
+                bool Ldirty = false;
+                if ((bounce == 0 || specularBounce) && sf.light >= 0) {
+                    const f3 le = light_L(sc.lights[sf.light], sf.n, -rd);
+                    const f3 add = beta * le;
+                    L4.x += add.x; L4.y += add.y; L4.z += add.z;
+                    Ldirty = true;
+                }
+                if (bounce < ps.maxDepth) {
+                    DBsdf bs;
+                    bsdf_init(bs, sf, sc.mats[sf.mat]);
+                    int px, py;
+                    uint32_t sLocal;
+                    Pcg rng;
+                    rng.inc = (path_sequence(cam, ps, pathId, px, py, sLocal) << 1u) | 1u;
+                    const uint2 st = pb.rng[pathId];
+                    rng.state = (uint64_t)st.x | ((uint64_t)st.y << 32);
+                    const f3 isectWo = normalize3(-rd);
+
+                    if (bsdf_num(bs, BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.nLights > 0) {
+                        // uniformSampleOneLight
+                        float selPdf;
+                        const int li = sample_light(sc, pcg_float(rng), selPdf);
+                        if (selPdf != 0) {
+                            const float ul0 = pcg_float(rng), ul1 = pcg_float(rng);
+                            const float us0 = pcg_float(rng), us1 = pcg_float(rng);
+                            const DevLight lt = sc.lights[li];
+                            const int flags = BSDF_ALL & ~BSDF_SPECULAR;
+                            // estimateDirect, light-sampling half
+                            f3 wi, pShape;
+                            float lightPdf = 0, scatteringPdf = 0;
+                            f3 Li = light_sample_Li(sc, lt, sf.p, ul0, ul1, wi, lightPdf, pShape);
+                            f3 A = mk3(0.f, 0.f, 0.f);
+                            bool haveShadow = false;
+                            f3 shD = mk3(0.f, 0.f, 0.f);
+                            if (lightPdf > 0 && !black3(Li)) {
+                                const f3 f = bsdf_f(bs, isectWo, wi, flags) * absdot3(wi, sf.n);
+                                scatteringPdf = bsdf_pdf(bs, isectWo, wi, flags);
+                                if (!black3(f)) {
+                                    const float weight = power_heuristic(lightPdf, scatteringPdf);
+                                    A = f * Li * weight / lightPdf;
+                                    haveShadow = true;
+                                    shD = normalize3(pShape - sf.p);   // Interaction::spawnRayTo -> Ray constructor
+                                }
+                            }
+                            // estimateDirect, BSDF-sampling half
+                            bool needProbe = false;
+                            f3 wi2 = mk3(0.f, 0.f, 0.f), fB = mk3(0.f, 0.f, 0.f);
+                            float weightB = 1, pdfB = scatteringPdf;
+                            {
+                                int sampledType = 0;
+                                f3 f2 = bsdf_sample(bs, isectWo, wi2, us0, us1, pdfB, sampledType, flags);
+                                f2 = f2 * absdot3(wi2, sf.n);
+                                const bool sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+                                if (!black3(f2) && pdfB > 0) {
+                                    bool go = true;
+                                    if (!sampledSpecular) {
+                                        const float lp = light_pdf_Li(sc, lt, sf.p, wi2);
+                                        if (lp == 0) go = false;
+                                        else weightB = power_heuristic(pdfB, lp);
+                                    }
+                                    if (go) { needProbe = true; fB = f2; }
+                                }
+                            }
+                            if (needProbe) {
+                                wantProbe = true;
+                                pr[0] = make_float4(sf.p.x, sf.p.y, sf.p.z, haveShadow ? 1.f : 0.f);
+                                pr[1] = make_float4(shD.x, shD.y, shD.z, __uint_as_float(pathId));
+                                pr[2] = make_float4(A.x, A.y, A.z, __int_as_float(li));
+                                pr[3] = make_float4(wi2.x, wi2.y, wi2.z, weightB);
+                                pr[4] = make_float4(fB.x, fB.y, fB.z, pdfB);
+                                pr[5] = make_float4(beta.x, beta.y, beta.z, selPdf);
+                            } else if (haveShadow) {
+                                // Ld = (0 + A) / selPdf, L += beta * Ld once the light is known to be visible
+                                const f3 c = beta * (A / selPdf);
+                                wantShadow = true;
+                                sA = make_float4(sf.p.x, sf.p.y, sf.p.z, shD.x);
+                                sB = make_float4(shD.y, shD.z, __uint_as_float(pathId), c.x);
+                                sC = make_float4(c.y, c.z, 0.f, 0.f);
+                            }
+                        }
+                    }
+
+                    // sample the BSDF for the next direction
+                    {
+                        const f3 wo = -rd;
+                        f3 wi = mk3(0.f, 0.f, 0.f);
+                        float pdf = 0;
+                        int flags = 0;
+                        const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+                        const f3 f = bsdf_sample(bs, wo, wi, u0, u1, pdf, flags, BSDF_ALL);
+                        if (!(black3(f) || pdf == 0.f)) {
+                            beta = beta * (f * absdot3(wi, sf.n) / pdf);
+                            const bool spec = (flags & BSDF_SPECULAR) != 0;
+                            if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                                const float eta = bs.eta;
+                                etaScale *= (dot3(wo, sf.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                            }
+                            const f3 nd = normalize3(wi);   // Interaction::spawnRay -> Ray constructor
+                            alive = true;
+                            const f3 rrBeta = beta * etaScale;
+                            const float mx = gmax(gmax(rrBeta.x, rrBeta.y), rrBeta.z);
+                            if (mx < ps.rrThreshold && bounce > 3) {
+                                const float q = gmax(.05f, 1 - mx);
+                                if (pcg_float(rng) < q) alive = false;
+                                else beta = beta / (1 - q);
+                            }
+                            if (alive) {
+                                nA = make_float4(sf.p.x, sf.p.y, sf.p.z, nd.x);
+                                nB = make_float4(nd.y, nd.z, __uint_as_float(pathId | (spec ? 0x80000000u : 0u)), 0.f);
+                                pb.beta[pathId] = make_float4(beta.x, beta.y, beta.z, 0.f);
+                                pb.rng[pathId] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                                if (etaScale != L4.w) { L4.w = etaScale; Ldirty = true; }
+                            }
+                        }
+                    }
+                }
+                if (Ldirty) pb.L[pathId] = L4;
+            }
+        }
+        const uint32_t slotN = wave_append(cntNext, alive);
+        if (alive) { pb.rayA[nxt][slotN] = nA; pb.rayB[nxt][slotN] = nB; }
+        const uint32_t slotS = wave_append(cntShadow, wantShadow);
+        if (wantShadow) { pb.shA[slotS] = sA; pb.shB[slotS] = sB; pb.shC[slotS] = sC; }
+        const uint32_t slotP = wave_append(cntProbe, wantProbe);
+        if (wantProbe) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pb.probe[(size_t)slotP * 6 + k] = pr[k];
+        }
+    }
+}
+
+// Shadow rays of the light-sampling half (VisibilityTester::unoccluded, Render/Light.cpp:28-31): any-hit
+// over Ray(p, pLight - p, 1 - ShadowEpsilon); a visible light adds its contribution to the path's L.
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    const uint32_t n = pb.counts[bounce * 4 + 1];
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    TravCounters cn = {0, 0, 0, 0};
+    uint32_t myRays = 0;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const float4 a = pb.shA[i], b = pb.shB[i], c = pb.shC[i];
+        RayCtx r;
+        ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+        HitRec h;
+        const bool occluded = kd_trace<false, STATS>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
+        if (!occluded) {
+            const uint32_t pathId = __float_as_uint(b.z);
+            float4 L4 = pb.L[pathId];
+            L4.x += b.w; L4.y += c.x; L4.z += c.y;
+            pb.L[pathId] = L4;
+        }
+        ++myRays;
+    }
+    if (STATS) flush_counters(stats, cn, myRays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
+}
+
+// Paths whose BSDF sample may see the chosen light (estimateDirect, Render/Render.cpp:266-310): resolve the
+// shadow ray of the light sample (if any) and the closest hit along the BSDF sample, then add
+// beta * ((A' + B') / selPdf) to the path's L with the reference's association.
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    const uint32_t n = pb.counts[bounce * 4 + 2];
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    TravCounters cn = {0, 0, 0, 0};
+    uint32_t myRays = 0, nShadow = 0;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const float4 e0 = pb.probe[(size_t)i * 6 + 0], e1 = pb.probe[(size_t)i * 6 + 1], e2 = pb.probe[(size_t)i * 6 + 2];
+        const float4 e3 = pb.probe[(size_t)i * 6 + 3], e4 = pb.probe[(size_t)i * 6 + 4], e5 = pb.probe[(size_t)i * 6 + 5];
+        const f3 p = mk3(e0.x, e0.y, e0.z);
+        const uint32_t pathId = __float_as_uint(e1.w);
+        const int li = __float_as_int(e2.w);
+        f3 Ld = mk3(0.f, 0.f, 0.f);
+        if (e0.w != 0.f) {
+            RayCtx r;
+            ray_setup(r, p, mk3(e1.x, e1.y, e1.z));
+            HitRec h;
+            const bool occluded = kd_trace<false, STATS>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
+            if (!occluded) Ld = Ld + mk3(e2.x, e2.y, e2.z);
+            ++myRays;
+            ++nShadow;
+        }
+        {
+            const f3 wi = mk3(e3.x, e3.y, e3.z);
+            RayCtx r;
+            ray_setup(r, p, normalize3(wi));
+            HitRec h;
+            const bool found = kd_trace<true, STATS>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+            ++myRays;
+            f3 Li = mk3(0.f, 0.f, 0.f);
+            if (found) {
+                Surf sf;
+                surface_at(sc, h.prim, h.b0, h.b1, h.b2, sf);
+                if (sf.light == li) Li = light_L(sc.lights[li], sf.n, -wi);
+            }
+            if (!black3(Li)) Ld = Ld + mk3(e4.x, e4.y, e4.z) * Li * mk3(1.f, 1.f, 1.f) * e3.w / e4.w;
+        }
+        const f3 add = mk3(e5.x, e5.y, e5.z) * (Ld / e5.w);
+        float4 L4 = pb.L[pathId];
+        L4.x += add.x; L4.y += add.y; L4.z += add.z;
+        pb.L[pathId] = L4;
+    }
+    if (STATS) flush_counters(stats, cn, myRays);
+    if (nShadow) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)nShadow);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+}
+
+// Sample filter of the render loop (Render/Render.cpp:72-83).
+RT_DEV f3 sanitize_L(f3 L) {
+    const float lum = 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z;
+    if (isnan(L.x) || isnan(L.y) || isnan(L.z)) return mk3(0.f, 0.f, 0.f);
+    if ((double)lum < -1e-5) return mk3(0.f, 0.f, 0.f);
+    if (isinf(lum)) return mk3(0.f, 0.f, 0.f);
+    return L;
+}
+
+// FilmTile::addSample for the 0.5-radius box filter (Object/Film.h:111-155): pixels [x0,x1) x [y0,y1)
+// receive L with weight 1. Returns true when that set is exactly the sample's own pixel.
+RT_DEV bool film_footprint(float pfx, float pfy, int px, int py, int &x0, int &y0, int &x1, int &y1) {
+    const float dx = pfx - 0.5f, dy = pfy - 0.5f;
+    x0 = (int)ceilf(dx - 0.5f);
+    y0 = (int)ceilf(dy - 0.5f);
+    x1 = (int)floorf(dx + 0.5f) + 1;
+    y1 = (int)floorf(dy + 0.5f) + 1;
+    return x0 == px && y0 == py && x1 == px + 1 && y1 == py + 1;
+}
+RT_DEV void film_spill(const CameraDev &cam, float *spillRgb, float *spillW, int px, int py, int x0, int y0, int x1, int y1, f3 L,
+                       f3 &own, float &ownW) {
+    for (int y = max(y0, 0); y < min(y1, cam.height); ++y)
+        for (int x = max(x0, 0); x < min(x1, cam.width); ++x) {
+            if (x == px && y == py) { own = own + L; ownW += 1.0f; continue; }
+            const size_t g = (size_t)y * cam.width + x;
+            atomicAdd(&spillRgb[3 * g + 0], L.x);
+            atomicAdd(&spillRgb[3 * g + 1], L.y);
+            atomicAdd(&spillRgb[3 * g + 2], L.z);
+            atomicAdd(&spillW[g], 1.0f);
+        }
+}
+
+// End of a pass: every pixel adds its samples of this pass to the film in sample order.
+__global__ __launch_bounds__(RT_BLOCK) void k_film_path(CameraDev cam, PassInfo ps, PathBuffers pb, float *rgbSum, float *weightSum,
+                                                        float *spillRgb, float *spillW) {
+    for (uint32_t pi = blockIdx.x * RT_BLOCK + threadIdx.x; pi < ps.nPix; pi += gridDim.x * RT_BLOCK) {
+        const uint32_t ly = pi / ps.sbW, lx = pi - ly * ps.sbW;
+        const int px = cam.sb[0] + (int)lx, py = cam.sb[1] + (int)ly;
+        const size_t g = (size_t)py * cam.width + px;
+        f3 acc = mk3(rgbSum[3 * g], rgbSum[3 * g + 1], rgbSum[3 * g + 2]);
+        float w = weightSum[g];
+        for (uint32_t s = 0; s < ps.sppPass; ++s) {
+            const uint32_t id = s * ps.nPix + pi;
+            const float4 L4 = pb.L[id];
+            const f3 L = sanitize_L(mk3(L4.x, L4.y, L4.z));
+            const uint64_t pix = (uint64_t)py * (uint64_t)cam.width + (uint64_t)px;
+            Pcg rng;
+            pcg_set_sequence(rng, counter_sequence(pix, ps.sppTotal, ps.sppBase + s, ps.seed));
+            const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+            int x0, y0, x1, y1;
+            if (film_footprint((float)px + u0, (float)py + u1, px, py, x0, y0, x1, y1)) {
+                acc = acc + L;
+                w += 1.0f;
+            } else {
+                film_spill(cam, spillRgb, spillW, px, py, x0, y0, x1, y1, L, acc, w);
+            }
+        }
+        rgbSum[3 * g] = acc.x; rgbSum[3 * g + 1] = acc.y; rgbSum[3 * g + 2] = acc.z;
+        weightSum[g] = w;
+    }
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_merge_spill(size_t nPix, float *rgbSum, float *weightSum, float *spillRgb, float *spillW) {
+    for (size_t g = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; g < nPix; g += (size_t)gridDim.x * RT_BLOCK) {
+        const float w = spillW[g];
+        if (w != 0.f) {
+            rgbSum[3 * g] += spillRgb[3 * g]; rgbSum[3 * g + 1] += spillRgb[3 * g + 1]; rgbSum[3 * g + 2] += spillRgb[3 * g + 2];
+            weightSum[g] += w;
+            spillRgb[3 * g] = spillRgb[3 * g + 1] = spillRgb[3 * g + 2] = 0.f;
+            spillW[g] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Whitted integrator (Render/Render.cpp:106-152, 473-532)
+// ---------------------------------------------------------------------------------------------------
+#define RT_WHITTED_MAX_FRAMES 32
+
+struct WFrame {
+    f3 L, f;
+    float absd, pdf;
+    int prim;
+    float b0, b1, b2;
+    f3 rd;
+    int stage;
+};
+
+// WhittedRenderer::Li with the recursion unrolled into explicit frames; evaluates children depth-first in
+// the reference's order (reflection before transmission) and combines them with its association
+// (L += f * Li(child) * |wi.n| / pdf). The frame at stack position k is the call at recursion depth k.
+// When `countOnly` is set nothing is shaded: the function only consumes the random numbers the full
+// evaluation would consume (the specular tree does not depend on them).
+template <bool STATS>
+RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f3 ro, f3 rdir, Pcg &rng, int maxDepth, bool countOnly,
+                     TravCounters &cn, uint32_t &nClosest, uint32_t &nAny) {
+    WFrame fr[RT_WHITTED_MAX_FRAMES];
+    int sp = 0;
+    f3 Lret = mk3(0.f, 0.f, 0.f);
+    enum { ENTER, ADVANCE, RETURN } state = ENTER;
+    for (;;) {
+        if (state == ENTER) {
+            // a call at depth == sp
+            RayCtx r;
+            ray_setup(r, ro, rdir);
+            HitRec h;
+            ++nClosest;
+            const bool hit = kd_trace<true, STATS>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+            Lret = mk3(0.f, 0.f, 0.f);
+            state = RETURN;
+            if (hit) {
+                Surf sf;
+                surface_at(sc, h.prim, h.b0, h.b1, h.b2, sf);
+                const f3 wo = normalize3(-rdir);
+                DBsdf bs;
+                bsdf_init(bs, sf, sc.mats[sf.mat]);
+                f3 L = mk3(0.f, 0.f, 0.f);
+                if (!countOnly && sf.light >= 0) L = L + light_L(sc.lights[sf.light], sf.n, wo);
+                for (uint32_t li = 0; li < sc.nLights; ++li) {
+                    const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+                    if (countOnly) continue;
+                    f3 wi, pShape;
+                    float pdf;
+                    const f3 Li = light_sample_Li(sc, sc.lights[li], sf.p, u0, u1, wi, pdf, pShape);
+                    if (black3(Li) || pdf == 0) continue;
+                    const f3 f = bsdf_f(bs, wo, wi, BSDF_ALL);
+                    if (!black3(f)) {
+                        RayCtx sr;
+                        ray_setup(sr, sf.p, normalize3(pShape - sf.p));
+                        HitRec sh;
+                        ++nAny;
+                        if (!kd_trace<false, STATS>(sc, tb, stk, threadIdx.x, sr, 1 - RT_SHADOW_EPS, sh, cn))
+                            L = L + f * Li * absdot3(wi, sf.n) / pdf;
+                    }
+                }
+                if (sp + 1 < maxDepth && sp < RT_WHITTED_MAX_FRAMES) {
+                    WFrame &f = fr[sp++];
+                    f.L = L;
+                    f.prim = h.prim; f.b0 = h.b0; f.b1 = h.b1; f.b2 = h.b2;
+                    f.rd = rdir;
+                    f.stage = 0;
+                    f.pdf = 0.f;
+                    state = ADVANCE;
+                } else {
+                    Lret = L;
+                }
+            }
+        } else if (state == ADVANCE) {
+            WFrame &f = fr[sp - 1];
+            if (f.stage == 2) {
+                Lret = f.L;
+                --sp;
+                state = RETURN;
+                continue;
+            }
+            // stage 0: specularReflect, stage 1: specularTransmit
+            Surf sf;
+            surface_at(sc, f.prim, f.b0, f.b1, f.b2, sf);
+            DBsdf bs;
+            bsdf_init(bs, sf, sc.mats[sf.mat]);
+            const f3 wo = normalize3(-f.rd);
+            const int type = (f.stage == 0 ? BSDF_REFLECTION : BSDF_TRANSMISSION) | BSDF_SPECULAR;
+            f.stage += 1;
+            f3 wi = mk3(0.f, 0.f, 0.f);
+            float pdf = 0;
+            int sampledType = 0;
+            const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+            const f3 fv = bsdf_sample(bs, wo, wi, u0, u1, pdf, sampledType, type);
+            if (pdf > 0.f && !black3(fv) && absdot3(wi, sf.n) != 0.f) {
+                f.f = fv;
+                f.absd = absdot3(wi, sf.n);
+                f.pdf = pdf;
+                ro = sf.p;
+                rdir = normalize3(wi);
+                state = ENTER;
+            }
+        } else {   // RETURN: a call finished with radiance Lret
+            if (sp == 0) return Lret;
+            WFrame &f = fr[sp - 1];
+            f.L = f.L + f.f * Lret * f.absd / f.pdf;
+            state = ADVANCE;
+        }
+    }
+}
+
+// Reference tile stream, step 1: one lane per 16x16 tile walks the tile's samples in the reference's
+// order (Render/Render.cpp:32-92) consuming random numbers exactly as the full evaluation would, and
+// records the PCG32 state at the first sample of every pixel.
+template <bool LDS_SCENE>
+__global__ __launch_bounds__(RT_BLOCK) void k_whitted_prepass(DevScene sc, CameraDev cam, int spp, int maxDepth, uint32_t nTiles, uint32_t ntx,
+                                                              uint2 *pixelState) {
+    extern __shared__ uint4 smem[];
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t t = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (t >= nTiles) return;
+    const int tx = (int)(t % ntx), ty = (int)(t / ntx);
+    const int x0 = cam.sb[0] + tx * 16, x1 = min(x0 + 16, cam.sb[2]);
+    const int y0 = cam.sb[1] + ty * 16, y1 = min(y0 + 16, cam.sb[3]);
+    const int sbW = cam.sb[2] - cam.sb[0];
+    Pcg rng;
+    pcg_set_sequence(rng, (uint64_t)t);
+    TravCounters cn = {0, 0, 0, 0};
+    uint32_t nc = 0, na = 0;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            pixelState[(size_t)(y - cam.sb[1]) * sbW + (x - cam.sb[0])] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+            for (int s = 0; s < spp; ++s) {
+                const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+                f3 o, d;
+                camera_ray(cam, (float)x + u0, (float)y + u1, o, d);
+                whitted_li<false>(sc, tb, stk, o, d, rng, maxDepth, true, cn, nc, na);
+            }
+        }
+}
+
+// Step 2 (and the whole job in counter mode): one lane per pixel evaluates its samples in order and adds
+// them to the film.
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam, int sppBegin, int sppEnd, int sppTotal, int maxDepth, int rngMode,
+                                                      uint64_t seed, const uint2 *pixelState, float *rgbSum, float *weightSum, float *spillRgb,
+                                                      float *spillW, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    const int sbW = cam.sb[2] - cam.sb[0], sbH = cam.sb[3] - cam.sb[1];
+    TravCounters cn = {0, 0, 0, 0};
+    uint32_t nc = 0, na = 0, ns = 0;
+    // pixels are visited tile by tile (16x16) so that a wave works on a compact screen region
+    const uint32_t ntx = (uint32_t)(sbW + 15) / 16, nty = (uint32_t)(sbH + 15) / 16;
+    const uint32_t nSlots = ntx * nty * 256u;
+    for (uint32_t pi = blockIdx.x * RT_BLOCK + threadIdx.x; pi < nSlots; pi += gridDim.x * RT_BLOCK) {
+        const uint32_t tile = pi / 256, inTile = pi % 256;
+        const int lx = (int)(tile % ntx) * 16 + (int)(inTile % 16), ly = (int)(tile / ntx) * 16 + (int)(inTile / 16);
+        if (lx >= sbW || ly >= sbH) continue;
+        const int px = cam.sb[0] + lx, py = cam.sb[1] + ly;
+        const size_t g = (size_t)py * cam.width + px;
+        f3 acc = mk3(rgbSum[3 * g], rgbSum[3 * g + 1], rgbSum[3 * g + 2]);
+        float w = weightSum[g];
+        Pcg rng;
+        if (rngMode == RT_RNG_REFERENCE_TILE_STREAM) {
+            const uint32_t tIdx = (uint32_t)(ly / 16) * ntx + (uint32_t)(lx / 16);
+            rng.inc = ((uint64_t)tIdx << 1u) | 1u;
+            const uint2 st = pixelState[(size_t)ly * sbW + lx];
+            rng.state = (uint64_t)st.x | ((uint64_t)st.y << 32);
+        }
+        for (int s = sppBegin; s < sppEnd; ++s) {
+            if (rngMode == RT_RNG_COUNTER)
+                pcg_set_sequence(rng, counter_sequence((uint64_t)py * (uint64_t)cam.width + (uint64_t)px, (uint32_t)sppTotal, (uint32_t)s, seed));
+            const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+            const float pfx = (float)px + u0, pfy = (float)py + u1;
+            f3 o, d;
+            camera_ray(cam, pfx, pfy, o, d);
+            f3 L = whitted_li<STATS>(sc, tb, stk, o, d, rng, maxDepth, false, cn, nc, na);
+            L = sanitize_L(L);
+            ++ns;
+            int fx0, fy0, fx1, fy1;
+            if (film_footprint(pfx, pfy, px, py, fx0, fy0, fx1, fy1)) {
+                acc = acc + L;
+                w += 1.0f;
+            } else {
+                film_spill(cam, spillRgb, spillW, px, py, fx0, fy0, fx1, fy1, L, acc, w);
+            }
+        }
+        rgbSum[3 * g] = acc.x; rgbSum[3 * g + 1] = acc.y; rgbSum[3 * g + 2] = acc.z;
+        weightSum[g] = w;
+    }
+    if (STATS) flush_counters(stats, cn, nc + na);
+    if (nc) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)nc);
+    if (na) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)na);
+    if (ns) atomicAdd(&stats[ST_CAMERA_SAMPLES], (unsigned long long)ns);
+}

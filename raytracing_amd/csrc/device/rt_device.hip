@@ -1,0 +1,668 @@
+// C ABI of the device library (include/raytracing_amd.h): context, scene upload, batch tracing, rendering.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/raytracing_amd.h"
+#include "kernels.h"
+
+namespace {
+
+std::string g_create_err;
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int numCUs = 256;
+    int gridBlocks = 2048;
+
+    // scene
+    bool haveScene = false;
+    DevScene sc{};
+    void *dNodes = nullptr, *dLeafIdx = nullptr, *dTriHot = nullptr, *dTriShade = nullptr, *dMats = nullptr, *dLights = nullptr;
+    void *dLightCdf = nullptr, *dLightFunc = nullptr;
+    bool ldsScene = false;
+    bool hasGlass = false;
+
+    // camera
+    bool haveCamera = false;
+    CameraDev cam{};
+
+    // stats
+    unsigned long long *dStats = nullptr;
+    std::vector<EventPair> extendEvents;
+    size_t extendEventsUsed = 0;
+    double renderMs = 0;
+
+    // path buffers
+    PathBuffers pb{};
+    size_t pbCapacity = 0;
+    int pbDepth = 0;
+    std::vector<void *> pbAllocs;
+
+    // film spill + whitted state
+    float *dSpillRgb = nullptr, *dSpillW = nullptr;
+    size_t spillPixels = 0;
+    uint2 *dPixelState = nullptr;
+    size_t pixelStateCap = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            return RT_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+int fail(rt_context *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+void free_scene(rt_context *c) {
+    void **ptrs[] = {&c->dNodes, &c->dLeafIdx, &c->dTriHot, &c->dTriShade, &c->dMats, &c->dLights, &c->dLightCdf, &c->dLightFunc};
+    for (void **p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->haveScene = false;
+}
+
+void free_path_buffers(rt_context *c) {
+    for (void *p : c->pbAllocs) (void)hipFree(p);
+    c->pbAllocs.clear();
+    c->pbCapacity = 0;
+    c->pbDepth = 0;
+    c->pb = PathBuffers{};
+}
+
+// Per-triangle constants of the surface part of ATriangleShape::hit (reference
+// src/core/Shape/TriangleShape.cpp:387-423,433): ss = normalize(dpdu), the geometric normal, and whether the
+// closest-hit flavour rejects the triangle as degenerate. They do not depend on the ray.
+void tri_constants(const float *p, const float *uvIn, f3 &ss, f3 &ng, bool &degenerate) {
+    const f3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
+    float uv[3][2] = {{0, 0}, {1, 0}, {1, 1}};
+    if (uvIn)
+        for (int k = 0; k < 3; ++k) { uv[k][0] = uvIn[2 * k]; uv[k][1] = uvIn[2 * k + 1]; }
+    const float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]}, duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
+    const f3 dp02 = p0 - p2, dp12 = p1 - p2;
+    const float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+    const bool degenerateUV = std::fabs(determinant) < 1e-8;
+    f3 dpdu = mk3(0, 0, 0), dpdv = mk3(0, 0, 0);
+    if (!degenerateUV) {
+        const float invdet = 1 / determinant;
+        dpdu = (duv12[1] * dp02 - duv02[1] * dp12) * invdet;
+        dpdv = (-duv12[0] * dp02 + duv02[0] * dp12) * invdet;
+    }
+    degenerate = false;
+    if (degenerateUV || dot3(cross3(dpdu, dpdv), cross3(dpdu, dpdv)) == 0) {
+        const f3 g = cross3(p2 - p0, p1 - p0);
+        if (dot3(g, g) == 0) {
+            degenerate = true;
+        } else {
+            const f3 v1 = normalize3(g);   // coordinateSystem (Utils/Math.h:454-461)
+            if (std::fabs(v1.x) > std::fabs(v1.y)) dpdu = mk3(-v1.z, 0, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+            else dpdu = mk3(0, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+        }
+    }
+    ss = normalize3(dpdu);
+    ng = normalize3(cross3(dp02, dp12));
+}
+
+template <typename T>
+int upload(rt_context *c, void **dst, const std::vector<T> &v, size_t padBytes = 16) {
+    size_t bytes = v.size() * sizeof(T);
+    size_t alloc = ((bytes + padBytes - 1) / padBytes) * padBytes + padBytes;
+    HIPCHK(c, hipMalloc(dst, alloc));
+    HIPCHK(c, hipMemset(*dst, 0, alloc));
+    if (bytes) HIPCHK(c, hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+size_t trace_lds_bytes(const rt_context *c) { return RT_STACK_LDS_BYTES + (c->ldsScene ? c->sc.ldsSceneBytes : 0); }
+
+int ensure_spill(rt_context *c) {
+    const size_t n = (size_t)c->cam.width * c->cam.height;
+    if (c->spillPixels == n && c->dSpillRgb) return RT_OK;
+    if (c->dSpillRgb) (void)hipFree(c->dSpillRgb);
+    if (c->dSpillW) (void)hipFree(c->dSpillW);
+    c->dSpillRgb = c->dSpillW = nullptr;
+    HIPCHK(c, hipMalloc((void **)&c->dSpillRgb, n * 3 * sizeof(float)));
+    HIPCHK(c, hipMalloc((void **)&c->dSpillW, n * sizeof(float)));
+    HIPCHK(c, hipMemset(c->dSpillRgb, 0, n * 3 * sizeof(float)));
+    HIPCHK(c, hipMemset(c->dSpillW, 0, n * sizeof(float)));
+    c->spillPixels = n;
+    return RT_OK;
+}
+
+int ensure_path_buffers(rt_context *c, size_t nPaths, int maxDepth) {
+    if (c->pbCapacity >= nPaths && c->pbDepth >= maxDepth) return RT_OK;
+    free_path_buffers(c);
+    auto alloc = [&](void **p, size_t bytes) -> int {
+        HIPCHK(c, hipMalloc(p, bytes));
+        c->pbAllocs.push_back(*p);
+        return RT_OK;
+    };
+    int rc;
+    PathBuffers &pb = c->pb;
+    for (int q = 0; q < 2; ++q) {
+        if ((rc = alloc((void **)&pb.rayA[q], nPaths * 16))) return rc;
+        if ((rc = alloc((void **)&pb.rayB[q], nPaths * 16))) return rc;
+    }
+    if ((rc = alloc((void **)&pb.hit, nPaths * 16))) return rc;
+    if ((rc = alloc((void **)&pb.L, nPaths * 16))) return rc;
+    if ((rc = alloc((void **)&pb.beta, nPaths * 16))) return rc;
+    if ((rc = alloc((void **)&pb.rng, nPaths * 8))) return rc;
+    if ((rc = alloc((void **)&pb.shA, nPaths * 16))) return rc;
+    if ((rc = alloc((void **)&pb.shB, nPaths * 16))) return rc;
+    if ((rc = alloc((void **)&pb.shC, nPaths * 16))) return rc;
+    if ((rc = alloc((void **)&pb.probe, nPaths * 16 * 6))) return rc;
+    if ((rc = alloc((void **)&pb.counts, (size_t)(maxDepth + 2) * 4 * sizeof(uint32_t)))) return rc;
+    c->pbCapacity = nPaths;
+    c->pbDepth = maxDepth;
+    return RT_OK;
+}
+
+EventPair *next_event_pair(rt_context *c) {
+    if (c->extendEventsUsed >= 200000) return nullptr;
+    if (c->extendEventsUsed == c->extendEvents.size()) {
+        EventPair ep;
+        if (hipEventCreate(&ep.a) != hipSuccess) return nullptr;
+        if (hipEventCreate(&ep.b) != hipSuccess) { (void)hipEventDestroy(ep.a); return nullptr; }
+        c->extendEvents.push_back(ep);
+    }
+    return &c->extendEvents[c->extendEventsUsed++];
+}
+
+template <typename... Args>
+void launch_trace_kernel(rt_context *c, bool stats, void (*kLdsStats)(Args...), void (*kLds)(Args...), void (*kGlobStats)(Args...),
+                         void (*kGlob)(Args...), int grid, Args... args) {
+    auto k = c->ldsScene ? (stats ? kLdsStats : kLds) : (stats ? kGlobStats : kGlob);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), trace_lds_bytes(c), c->stream, args...);
+}
+
+int trace_closest_dev(rt_context *c, uint64_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary,
+                      bool stats) {
+    if (n == 0) return RT_OK;
+    const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)c->gridBlocks);
+    launch_trace_kernel(c, stats, k_trace_closest<true, true>, k_trace_closest<true, false>, k_trace_closest<false, true>,
+                        k_trace_closest<false, false>, grid, c->sc, n, o, d, tmax, prim, t, bary, c->dStats);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+int trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, const float *tmax, uint8_t *occ, bool stats) {
+    if (n == 0) return RT_OK;
+    const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)c->gridBlocks);
+    launch_trace_kernel(c, stats, k_trace_any<true, true>, k_trace_any<true, false>, k_trace_any<false, true>, k_trace_any<false, false>, grid,
+                        c->sc, n, o, d, tmax, occ, c->dStats);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+int check_render_args(rt_context *c, const rt_render_params *p) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!p) return fail(c, RT_ERR_INVALID_ARG, "params is NULL");
+    if (!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (!c->haveCamera) return fail(c, RT_ERR_NO_CAMERA, "no camera set");
+    if (p->integrator != RT_INTEGRATOR_PATH && p->integrator != RT_INTEGRATOR_WHITTED) return fail(c, RT_ERR_INVALID_ARG, "unknown integrator");
+    if (p->spp_total <= 0 || p->spp_begin < 0 || p->spp_end > p->spp_total || p->spp_begin > p->spp_end)
+        return fail(c, RT_ERR_INVALID_ARG, "bad sample range");
+    if (p->max_depth < 0 || p->max_depth > 1024) return fail(c, RT_ERR_INVALID_ARG, "bad max_depth");
+    if (p->rng_mode != RT_RNG_COUNTER && p->rng_mode != RT_RNG_REFERENCE_TILE_STREAM) return fail(c, RT_ERR_INVALID_ARG, "unknown rng_mode");
+    if (p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM) {
+        if (p->integrator == RT_INTEGRATOR_PATH)
+            return fail(c, RT_ERR_UNSUPPORTED, "the reference tile stream is serial per tile; the wavefront path tracer uses RT_RNG_COUNTER");
+        if (p->spp_begin != 0 || p->spp_end != p->spp_total)
+            return fail(c, RT_ERR_INVALID_ARG, "the reference tile stream cannot be split by sample index");
+    }
+    if (p->integrator == RT_INTEGRATOR_WHITTED && p->max_depth > RT_WHITTED_MAX_FRAMES)
+        return fail(c, RT_ERR_UNSUPPORTED, "Whitted max_depth above 32 is not supported");
+    return RT_OK;
+}
+
+int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    const CameraDev &cam = c->cam;
+    const uint32_t sbW = (uint32_t)(cam.sb[2] - cam.sb[0]), sbH = (uint32_t)(cam.sb[3] - cam.sb[1]);
+    const uint64_t nPix = (uint64_t)sbW * sbH;
+    if (nPix == 0 || p->spp_end == p->spp_begin) return RT_OK;
+    int sppPass = p->spp_per_pass;
+    if (sppPass <= 0) sppPass = (int)std::max<uint64_t>(1, (1ull << 24) / nPix);
+    sppPass = std::min(sppPass, p->spp_end - p->spp_begin);
+    if (nPix * (uint64_t)sppPass >= (1ull << 30)) sppPass = (int)std::max<uint64_t>(1, ((1ull << 30) - 1) / nPix);
+    if (nPix >= (1ull << 30)) return fail(c, RT_ERR_UNSUPPORTED, "film too large");
+    int rc;
+    if ((rc = ensure_path_buffers(c, nPix * (uint64_t)sppPass, p->max_depth))) return rc;
+    if ((rc = ensure_spill(c))) return rc;
+    const bool stats = p->collect_stats != 0;
+    const size_t lds = trace_lds_bytes(c);
+    const int grid = c->gridBlocks;
+    PathBuffers &pb = c->pb;
+
+    for (int s0 = p->spp_begin; s0 < p->spp_end; s0 += sppPass) {
+        PassInfo ps;
+        ps.nPix = (uint32_t)nPix;
+        ps.sbW = sbW;
+        ps.sppPass = (uint32_t)std::min(sppPass, p->spp_end - s0);
+        ps.sppBase = (uint32_t)s0;
+        ps.sppTotal = (uint32_t)p->spp_total;
+        ps.seed = p->seed;
+        ps.maxDepth = p->max_depth;
+        ps.rrThreshold = p->rr_threshold;
+        HIPCHK(c, hipMemsetAsync(pb.counts, 0, (size_t)(p->max_depth + 2) * 4 * sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, c->stream, cam, ps, pb, c->dStats);
+        for (int b = 0; b <= p->max_depth; ++b) {
+            const int cur = b & 1;
+            EventPair *ep = next_event_pair(c);
+            if (ep) HIPCHK(c, hipEventRecord(ep->a, c->stream));
+            {
+                auto k = c->ldsScene ? (stats ? k_extend<true, true> : k_extend<true, false>) : (stats ? k_extend<false, true> : k_extend<false, false>);
+                hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, (const float4 *)pb.rayA[cur], (const float4 *)pb.rayB[cur],
+                                   pb.hit, (const uint32_t *)&pb.counts[b * 4], c->dStats);
+            }
+            if (ep) HIPCHK(c, hipEventRecord(ep->b, c->stream));
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->sc, cam, ps, pb, b);
+            if (b < p->max_depth) {
+                auto ks = c->ldsScene ? (stats ? k_shadow<true, true> : k_shadow<true, false>) : (stats ? k_shadow<false, true> : k_shadow<false, false>);
+                hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, pb, b, c->dStats);
+                auto kp = c->ldsScene ? (stats ? k_probe<true, true> : k_probe<true, false>) : (stats ? k_probe<false, true> : k_probe<false, false>);
+                hipLaunchKernelGGL(kp, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, pb, b, c->dStats);
+            }
+        }
+        hipLaunchKernelGGL(k_film_path, dim3(grid), dim3(RT_BLOCK), 0, c->stream, cam, ps, pb, rgb, wsum, c->dSpillRgb, c->dSpillW);
+        HIPCHK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_merge_spill, dim3(grid), dim3(RT_BLOCK), 0, c->stream, (size_t)cam.width * cam.height, rgb, wsum, c->dSpillRgb, c->dSpillW);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    const CameraDev &cam = c->cam;
+    const int sbW = cam.sb[2] - cam.sb[0], sbH = cam.sb[3] - cam.sb[1];
+    if (sbW <= 0 || sbH <= 0 || p->spp_end == p->spp_begin) return RT_OK;
+    int rc;
+    if ((rc = ensure_spill(c))) return rc;
+    const bool stats = p->collect_stats != 0;
+    const size_t lds = trace_lds_bytes(c);
+    const uint32_t ntx = (uint32_t)(sbW + 15) / 16, nty = (uint32_t)(sbH + 15) / 16;
+    const uint32_t nTiles = ntx * nty;
+    if (p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM) {
+        const size_t need = (size_t)sbW * sbH;
+        if (c->pixelStateCap < need) {
+            if (c->dPixelState) (void)hipFree(c->dPixelState);
+            c->dPixelState = nullptr;
+            HIPCHK(c, hipMalloc((void **)&c->dPixelState, need * sizeof(uint2)));
+            c->pixelStateCap = need;
+        }
+        auto k = c->ldsScene ? k_whitted_prepass<true> : k_whitted_prepass<false>;
+        // one lane per tile: spread the lanes over many small groups of waves
+        hipLaunchKernelGGL(k, dim3((nTiles + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, c->stream, c->sc, cam, p->spp_total, p->max_depth,
+                           nTiles, ntx, c->dPixelState);
+        HIPCHK(c, hipGetLastError());
+    }
+    const uint32_t nSlots = nTiles * 256u;
+    const int grid = (int)std::min<uint32_t>((nSlots + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)c->gridBlocks * 4u);
+    auto k = c->ldsScene ? (stats ? k_whitted<true, true> : k_whitted<true, false>) : (stats ? k_whitted<false, true> : k_whitted<false, false>);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, cam, p->spp_begin, p->spp_end, p->spp_total, p->max_depth, p->rng_mode,
+                       p->seed, (const uint2 *)c->dPixelState, rgb, wsum, c->dSpillRgb, c->dSpillW, c->dStats);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_merge_spill, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, (size_t)cam.width * cam.height, rgb, wsum, c->dSpillRgb,
+                       c->dSpillW);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_version(void) { return "raytracing_amd 0.1 (gfx950)"; }
+
+const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int rt_create(int device_id, rt_context **out) {
+    if (!out) { g_create_err = "out_ctx is NULL"; return RT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_err = std::string("no HIP device is visible (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                       "); this library has no CPU fallback";
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) { g_create_err = "device_id out of range"; return RT_ERR_INVALID_ARG; }
+    auto *c = new rt_context();
+    c->device = device_id;
+    auto bail = [&](const char *what, hipError_t err) {
+        g_create_err = std::string(what) + ": " + hipGetErrorString(err);
+        delete c;
+        return RT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->gridBlocks = c->numCUs * 8;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipMalloc((void **)&c->dStats, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->dStats, 0, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_path_buffers(c);
+    if (c->dStats) (void)hipFree(c->dStats);
+    if (c->dSpillRgb) (void)hipFree(c->dSpillRgb);
+    if (c->dSpillW) (void)hipFree(c->dSpillW);
+    if (c->dPixelState) (void)hipFree(c->dPixelState);
+    for (auto &ep : c->extendEvents) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!d || !d->nodes || !d->tri_p || !d->material_id || !d->light_id || !d->materials || d->n_nodes == 0 || d->n_prims == 0 ||
+        d->n_materials == 0 || (d->n_leaf_idx && !d->leaf_idx) || (d->n_lights && !d->lights))
+        return fail(c, RT_ERR_INVALID_ARG, "scene description has NULL or empty required arrays");
+    // validate everything a kernel will index with
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        if (d->shape_type && d->shape_type[i] != RT_SHAPE_TRIANGLE) return fail(c, RT_ERR_UNSUPPORTED, "only triangle shapes are supported");
+        if (d->material_id[i] < 0 || (uint32_t)d->material_id[i] >= d->n_materials) return fail(c, RT_ERR_INVALID_ARG, "material_id out of range");
+        if (d->light_id[i] >= (int32_t)d->n_lights) return fail(c, RT_ERR_INVALID_ARG, "light_id out of range");
+    }
+    for (uint32_t i = 0; i < d->n_lights; ++i)
+        if (d->lights[i].prim_id < 0 || (uint32_t)d->lights[i].prim_id >= d->n_prims) return fail(c, RT_ERR_INVALID_ARG, "light prim_id out of range");
+    for (uint32_t i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].type < RT_MAT_LAMBERTIAN || d->materials[i].type > RT_MAT_GLASS) return fail(c, RT_ERR_INVALID_ARG, "unknown material type");
+    for (uint32_t i = 0; i < d->n_nodes; ++i) {
+        const uint32_t w0 = d->nodes[2 * i], w1 = d->nodes[2 * i + 1];
+        if ((w1 & 3u) == 3u) {
+            const uint32_t n = w1 >> 2;
+            if (n == 1) { if (w0 >= d->n_prims) return fail(c, RT_ERR_INVALID_ARG, "leaf primitive index out of range"); }
+            else if (n > 1 && ((uint64_t)w0 + n > d->n_leaf_idx)) return fail(c, RT_ERR_INVALID_ARG, "leaf index range out of bounds");
+        } else {
+            const uint32_t above = w1 >> 2;
+            if (i + 1 >= d->n_nodes || above >= d->n_nodes || above <= i) return fail(c, RT_ERR_INVALID_ARG, "interior node child out of range");
+        }
+    }
+    for (uint32_t i = 0; i < d->n_leaf_idx; ++i)
+        if (d->leaf_idx[i] < 0 || (uint32_t)d->leaf_idx[i] >= d->n_prims) return fail(c, RT_ERR_INVALID_ARG, "leaf_idx entry out of range");
+
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+
+    const uint32_t np = d->n_prims;
+    std::vector<float4> hot((size_t)np * 3), shade((size_t)np * 5);
+    for (uint32_t i = 0; i < np; ++i) {
+        const float *p = &d->tri_p[9 * (size_t)i];
+        f3 ss, ng;
+        bool degenerate;
+        tri_constants(p, d->tri_uv ? &d->tri_uv[6 * (size_t)i] : nullptr, ss, ng, degenerate);
+        hot[3 * (size_t)i + 0] = make_float4(p[0], p[1], p[2], degenerate ? 1.f : 0.f);
+        hot[3 * (size_t)i + 1] = make_float4(p[3], p[4], p[5], 0.f);
+        hot[3 * (size_t)i + 2] = make_float4(p[6], p[7], p[8], 0.f);
+        const bool hasN = d->tri_n && (!d->tri_has_n || d->tri_has_n[i]);
+        const float *nn = hasN ? &d->tri_n[9 * (size_t)i] : nullptr;
+        shade[5 * (size_t)i + 0] = make_float4(nn ? nn[0] : 0.f, nn ? nn[1] : 0.f, nn ? nn[2] : 0.f, ss.x);
+        shade[5 * (size_t)i + 1] = make_float4(nn ? nn[3] : 0.f, nn ? nn[4] : 0.f, nn ? nn[5] : 0.f, ss.y);
+        shade[5 * (size_t)i + 2] = make_float4(nn ? nn[6] : 0.f, nn ? nn[7] : 0.f, nn ? nn[8] : 0.f, ss.z);
+        shade[5 * (size_t)i + 3] = make_float4(ng.x, ng.y, ng.z, hasN ? 1.f : 0.f);
+        float mi, li;
+        std::memcpy(&mi, &d->material_id[i], 4);
+        std::memcpy(&li, &d->light_id[i], 4);
+        shade[5 * (size_t)i + 4] = make_float4(mi, li, 0.f, 0.f);
+    }
+    std::vector<DevMaterial> mats(d->n_materials);
+    c->hasGlass = false;
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        mats[i] = DevMaterial{d->materials[i].rgb[0], d->materials[i].rgb[1], d->materials[i].rgb[2], d->materials[i].eta, d->materials[i].type, 0, 0, 0};
+        if (d->materials[i].type == RT_MAT_GLASS) c->hasGlass = true;
+    }
+    std::vector<DevLight> lights(d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        const rt_light &l = d->lights[i];
+        const float *p = &d->tri_p[9 * (size_t)l.prim_id];
+        const f3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
+        const f3 cr = cross3(p1 - p0, p2 - p0);
+        const float area = (float)(0.5 * std::sqrt(dot3(cr, cr)));   // ATriangleShape::area (TriangleShape.cpp:153-160)
+        lights[i] = DevLight{l.emit[0], l.emit[1], l.emit[2], l.two_sided, l.prim_id, area, 0.f, 0.f};
+    }
+    // UniformLightDistribution / Distribution1D (Utils/LightDistrib.cpp:17-21, LightDistrib.h:14-33)
+    const int nl = (int)d->n_lights;
+    std::vector<float> func(std::max(nl, 1), 1.0f), cdf(nl + 1, 0.f);
+    float funcInt = 0;
+    if (nl > 0) {
+        for (int i = 1; i < nl + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / nl;
+        funcInt = cdf[nl];
+        if (funcInt == 0) for (int i = 1; i < nl + 1; ++i) cdf[i] = float(i) / float(nl);
+        else for (int i = 1; i < nl + 1; ++i) cdf[i] /= funcInt;
+    }
+
+    std::vector<uint32_t> nodes(d->nodes, d->nodes + 2 * (size_t)d->n_nodes);
+    std::vector<int32_t> leafIdx;
+    if (d->n_leaf_idx) leafIdx.assign(d->leaf_idx, d->leaf_idx + d->n_leaf_idx);
+    int rc;
+    if ((rc = upload(c, &c->dNodes, nodes))) return rc;
+    if ((rc = upload(c, &c->dLeafIdx, leafIdx))) return rc;
+    if ((rc = upload(c, &c->dTriHot, hot))) return rc;
+    if ((rc = upload(c, &c->dTriShade, shade))) return rc;
+    if ((rc = upload(c, &c->dMats, mats))) return rc;
+    if ((rc = upload(c, &c->dLights, lights))) return rc;
+    if ((rc = upload(c, &c->dLightCdf, cdf))) return rc;
+    if ((rc = upload(c, &c->dLightFunc, func))) return rc;
+
+    DevScene &sc = c->sc;
+    sc.nodes = (const uint2 *)c->dNodes;
+    sc.leafIdx = (const int *)c->dLeafIdx;
+    sc.triHot = (const float4 *)c->dTriHot;
+    sc.triShade = (const float4 *)c->dTriShade;
+    sc.mats = (const DevMaterial *)c->dMats;
+    sc.lights = (const DevLight *)c->dLights;
+    sc.lightCdf = (const float *)c->dLightCdf;
+    sc.lightFunc = (const float *)c->dLightFunc;
+    for (int k = 0; k < 3; ++k) { sc.bmin[k] = d->bounds[k]; sc.bmax[k] = d->bounds[3 + k]; }
+    sc.nNodes = d->n_nodes;
+    sc.nLeafIdx = d->n_leaf_idx;
+    sc.nPrims = np;
+    sc.nMats = d->n_materials;
+    sc.nLights = d->n_lights;
+    sc.lightFuncInt = funcInt;
+    const size_t ldsBytes = (((size_t)d->n_nodes * 8 + 15) / 16 + ((size_t)d->n_leaf_idx * 4 + 15) / 16 + (size_t)np * 3) * 16;
+    c->ldsScene = ldsBytes <= 40 * 1024;
+    sc.ldsSceneBytes = c->ldsScene ? (uint32_t)ldsBytes : 0;
+    c->haveScene = true;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_context *c, const float r2c[16], const float c2w[16], int width, int height, const int sb[4]) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!r2c || !c2w || !sb || width <= 0 || height <= 0) return fail(c, RT_ERR_INVALID_ARG, "bad camera argument");
+    if (sb[0] < 0 || sb[1] < 0 || sb[2] > width || sb[3] > height || sb[0] > sb[2] || sb[1] > sb[3])
+        return fail(c, RT_ERR_INVALID_ARG, "sample bounds must lie inside the film");
+    std::memcpy(c->cam.r2c, r2c, 64);
+    std::memcpy(c->cam.c2w, c2w, 64);
+    c->cam.width = width;
+    c->cam.height = height;
+    std::memcpy(c->cam.sb, sb, 16);
+    c->haveCamera = true;
+    return RT_OK;
+}
+
+int rt_trace_closest_dev(rt_context *c, uint64_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (n && (!o || !d)) return fail(c, RT_ERR_INVALID_ARG, "ray arrays are NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return trace_closest_dev(c, n, o, d, tmax, prim, t, bary, false);
+}
+
+int rt_trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, const float *tmax, uint8_t *occ) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (n && (!o || !d || !occ)) return fail(c, RT_ERR_INVALID_ARG, "ray or output arrays are NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return trace_any_dev(c, n, o, d, tmax, occ, false);
+}
+
+int rt_trace_closest(rt_context *c, uint64_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return RT_OK;
+    if (!o || !d) return fail(c, RT_ERR_INVALID_ARG, "ray arrays are NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *dO = nullptr, *dD = nullptr, *dT = nullptr, *dt = nullptr, *dB = nullptr;
+    int32_t *dP = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() { for (void *p : {(void *)dO, (void *)dD, (void *)dT, (void *)dt, (void *)dB, (void *)dP}) if (p) (void)hipFree(p); };
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return RT_ERR_HIP; } } while (0)
+    CK(hipMalloc((void **)&dO, n * 12));
+    CK(hipMalloc((void **)&dD, n * 12));
+    CK(hipMemcpy(dO, o, n * 12, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dD, d, n * 12, hipMemcpyHostToDevice));
+    if (tmax) { CK(hipMalloc((void **)&dT, n * 4)); CK(hipMemcpy(dT, tmax, n * 4, hipMemcpyHostToDevice)); }
+    if (prim) CK(hipMalloc((void **)&dP, n * 4));
+    if (t) CK(hipMalloc((void **)&dt, n * 4));
+    if (bary) CK(hipMalloc((void **)&dB, n * 12));
+    rc = trace_closest_dev(c, n, dO, dD, dT, dP, dt, dB, true);
+    if (rc == RT_OK) {
+        CK(hipStreamSynchronize(c->stream));
+        if (prim) CK(hipMemcpy(prim, dP, n * 4, hipMemcpyDeviceToHost));
+        if (t) CK(hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost));
+        if (bary) CK(hipMemcpy(bary, dB, n * 12, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+    return rc;
+}
+
+int rt_trace_any(rt_context *c, uint64_t n, const float *o, const float *d, const float *tmax, uint8_t *occ) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return RT_OK;
+    if (!o || !d || !occ) return fail(c, RT_ERR_INVALID_ARG, "ray or output arrays are NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *dO = nullptr, *dD = nullptr, *dT = nullptr;
+    uint8_t *dOcc = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() { for (void *p : {(void *)dO, (void *)dD, (void *)dT, (void *)dOcc}) if (p) (void)hipFree(p); };
+    CK(hipMalloc((void **)&dO, n * 12));
+    CK(hipMalloc((void **)&dD, n * 12));
+    CK(hipMemcpy(dO, o, n * 12, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dD, d, n * 12, hipMemcpyHostToDevice));
+    if (tmax) { CK(hipMalloc((void **)&dT, n * 4)); CK(hipMemcpy(dT, tmax, n * 4, hipMemcpyHostToDevice)); }
+    CK(hipMalloc((void **)&dOcc, n));
+    rc = trace_any_dev(c, n, dO, dD, dT, dOcc, true);
+    if (rc == RT_OK) {
+        CK(hipStreamSynchronize(c->stream));
+        CK(hipMemcpy(occ, dOcc, n, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+    return rc;
+}
+
+int rt_render_dev(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    int rc = check_render_args(c, p);
+    if (rc) return rc;
+    if (!rgb || !wsum) return fail(c, RT_ERR_INVALID_ARG, "output buffers are NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return p->integrator == RT_INTEGRATOR_PATH ? render_path(c, p, rgb, wsum) : render_whitted(c, p, rgb, wsum);
+}
+
+int rt_render(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    int rc = check_render_args(c, p);
+    if (rc) return rc;
+    if (!rgb || !wsum) return fail(c, RT_ERR_INVALID_ARG, "output buffers are NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->cam.width * c->cam.height;
+    float *dRgb = nullptr, *dW = nullptr;
+    auto cleanup = [&]() { if (dRgb) (void)hipFree(dRgb); if (dW) (void)hipFree(dW); };
+    CK(hipMalloc((void **)&dRgb, n * 12));
+    CK(hipMalloc((void **)&dW, n * 4));
+    CK(hipMemcpy(dRgb, rgb, n * 12, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW, wsum, n * 4, hipMemcpyHostToDevice));
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = p->integrator == RT_INTEGRATOR_PATH ? render_path(c, p, dRgb, dW) : render_whitted(c, p, dRgb, dW);
+    if (rc == RT_OK) {
+        CK(hipStreamSynchronize(c->stream));
+        c->renderMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        CK(hipMemcpy(rgb, dRgb, n * 12, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(wsum, dW, n * 4, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+    return rc;
+}
+#undef CK
+
+int rt_synchronize(rt_context *c) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+void *rt_stream(rt_context *c) { return c ? (void *)c->stream : nullptr; }
+
+int rt_get_stats(rt_context *c, rt_stats *out) {
+    if (!c || !out) return RT_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[ST_COUNT];
+    HIPCHK(c, hipMemcpy(h, c->dStats, sizeof h, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->rays_closest = h[ST_RAYS_CLOSEST];
+    out->rays_any = h[ST_RAYS_ANY];
+    out->camera_samples = h[ST_CAMERA_SAMPLES];
+    out->n_interior = h[ST_INTERIOR];
+    out->n_leaf = h[ST_LEAF];
+    out->n_leaf_idx = h[ST_LEAFIDX];
+    out->n_tri_tests = h[ST_TRI];
+    out->counted_rays = h[ST_COUNTED_RAYS];
+    out->extend_rays = h[ST_EXTEND_RAYS];
+    double ms = 0;
+    for (size_t i = 0; i < c->extendEventsUsed; ++i) {
+        float m = 0;
+        if (hipEventElapsedTime(&m, c->extendEvents[i].a, c->extendEvents[i].b) == hipSuccess) ms += m;
+    }
+    out->extend_launches = c->extendEventsUsed;
+    out->extend_ms = ms;
+    out->render_ms = c->renderMs;
+    return RT_OK;
+}
+
+int rt_reset_stats(rt_context *c) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemset(c->dStats, 0, ST_COUNT * sizeof(unsigned long long)));
+    c->extendEventsUsed = 0;
+    c->renderMs = 0;
+    return RT_OK;
+}
+
+// Host evaluation of the device's sin/cos for the concentric disk mapping, for CPU-side accuracy tests.
+void rt_debug_sincos_disk(float theta, float *s, float *c) { sincos_disk(theta, *s, *c); }
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+"""Seeded ray batches shared by CPU and GPU parity tests."""
+import numpy as np
+
+
+def camera_rays(oracle, cfg, n, seed):
+    """Jittered camera rays through the oracle's restatement of Camera::castingRay."""
+    rs = np.random.RandomState(seed)
+    xy = np.stack([rs.uniform(0, cfg.width, n), rs.uniform(0, cfg.height, n)], 1).astype(np.float32)
+    return oracle.camera_rays(xy)
+
+
+def incoherent_rays(bounds, n, seed, slack=0.0):
+    """Origins uniform in the scene bounds (optionally inflated), directions uniform on the sphere."""
+    rs = np.random.RandomState(seed)
+    lo, hi = np.asarray(bounds[:3], np.float64), np.asarray(bounds[3:], np.float64)
+    ext = hi - lo
+    o = (lo - slack * ext + rs.uniform(0, 1, (n, 3)) * ext * (1 + 2 * slack)).astype(np.float32)
+    z = rs.uniform(-1, 1, n)
+    phi = rs.uniform(0, 2 * np.pi, n)
+    r = np.sqrt(np.maximum(0, 1 - z * z))
+    d = np.stack([r * np.cos(phi), r * np.sin(phi), z], 1).astype(np.float32)
+    d /= np.sqrt((d.astype(np.float32) ** 2).sum(1, keepdims=True)).astype(np.float32)
+    return o, d.astype(np.float32)
+
+
+def surface_rays(oracle, o, d, seed):
+    """Second-generation rays that start exactly ON surfaces: hit points of (o, d) with fresh random directions.
+    These exercise the self-intersection guard (the reference never offsets ray origins)."""
+    prim, t, bary = oracle.trace_closest(o, d)
+    keep = prim >= 0
+    tri = oracle.scene.tri_p[prim[keep]].reshape(-1, 3, 3)
+    b = bary[keep]
+    p = (b[:, 0:1] * tri[:, 0] + b[:, 1:2] * tri[:, 1]) + b[:, 2:3] * tri[:, 2]
+    _, d2 = incoherent_rays((0, 0, 0, 1, 1, 1), int(keep.sum()), seed)
+    return p.astype(np.float32), d2
+
+
+def axis_rays(bounds, n, seed):
+    """Axis-parallel rays (zero direction components make 1/d infinite and 0*inf NaN in the slab tests)."""
+    rs = np.random.RandomState(seed)
+    lo, hi = np.asarray(bounds[:3], np.float64), np.asarray(bounds[3:], np.float64)
+    o = (lo + rs.uniform(-0.1, 1.1, (n, 3)) * (hi - lo)).astype(np.float32)
+    d = np.zeros((n, 3), np.float32)
+    ax = rs.randint(0, 3, n)
+    d[np.arange(n), ax] = rs.choice([-1.0, 1.0], n)
+    return o, d
+
+
+def triangle_soup(n_tris, seed, lo=50.0, hi=500.0, emin=0.5, emax=5.0):
+    """Random small triangles: centres uniform in [lo,hi]^3, edge vectors of length in [emin, emax]."""
+    rs = np.random.RandomState(seed)
+    c = rs.uniform(lo, hi, (n_tris, 1, 3))
+    e = rs.normal(size=(n_tris, 3, 3))
+    e /= np.linalg.norm(e, axis=2, keepdims=True)
+    e *= rs.uniform(emin, emax, (n_tris, 3, 1))
+    return (c + e).astype(np.float32).reshape(n_tris, 9)
