@@ -438,14 +438,21 @@ bool kdHitAny(const Scene &s, const Ray &ray, Counters *cn) {
 // ------------------------------------------------------------------------------------------------
 // sampling warps (Render/Sampler.cpp:120-148, Sampler.h:71-89)
 // ------------------------------------------------------------------------------------------------
+// 0: libm cosf/sinf, as the reference calls them through glm (implementation-defined last bits: glibc's differ
+// from the correctly rounded value for ~1.3 % of arguments). 1: cos/sin evaluated in double and rounded once to
+// float, i.e. correctly rounded — what the HIP kernels compute — so that GPU and oracle agree bit for bit.
+std::atomic<int> g_trigMode{0};
+inline float trigCos(float x) { return g_trigMode.load(std::memory_order_relaxed) ? (float)std::cos((double)x) : std::cos(x); }
+inline float trigSin(float x) { return g_trigMode.load(std::memory_order_relaxed) ? (float)std::sin((double)x) : std::sin(x); }
+
 void concentricSampleDisk(const float u[2], float out[2]) {
     float ox = 2.f * u[0] - 1, oy = 2.f * u[1] - 1;
     if (ox == 0 && oy == 0) { out[0] = 0; out[1] = 0; return; }
     float theta, r;
     if (std::fabs(ox) > std::fabs(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
     else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
-    out[0] = r * std::cos(theta);
-    out[1] = r * std::sin(theta);
+    out[0] = r * trigCos(theta);
+    out[1] = r * trigSin(theta);
 }
 vec3 cosineSampleHemisphere(const float u[2]) {
     float d[2];
@@ -1087,6 +1094,8 @@ int oracle_render(const oracle_scene *o, const rt_render_params *p, float *rgb_s
     }
     return 0;
 }
+
+void oracle_set_trig_mode(int correctly_rounded) { g_trigMode.store(correctly_rounded ? 1 : 0); }
 
 // PCG32 stream check: first n floats of sequence `seq`.
 void oracle_rng_floats(uint64_t seq, int n, float *out) {

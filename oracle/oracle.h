@@ -33,6 +33,8 @@ int oracle_camera_rays(const oracle_scene *o, uint64_t n, const float *film_xy, 
 int oracle_render(const oracle_scene *o, const rt_render_params *p, float *rgb_sum, float *weight_sum, int n_threads,
                   oracle_render_stats *stats_out);
 void oracle_rng_floats(uint64_t seq, int n, float *out);
+/* 0 (default): libm cosf/sinf like the reference; 1: correctly rounded cos/sin (matches the HIP kernels bit for bit). */
+void oracle_set_trig_mode(int correctly_rounded);
 
 #ifdef __cplusplus
 }

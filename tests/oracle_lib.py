@@ -45,6 +45,7 @@ def lib():
         l.oracle_camera_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         l.oracle_render.argtypes = [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         l.oracle_rng_floats.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+        l.oracle_set_trig_mode.argtypes = [C.c_int]
         _lib = l
     return _lib
 
@@ -142,6 +143,11 @@ class Oracle:
         rc = self._l.oracle_render(self._h, C.byref(p), rgb.ctypes.data, w.ctypes.data, threads, C.addressof(st))
         assert rc == 0
         return rgb, w, st.as_dict()
+
+
+def set_trig_mode(correctly_rounded):
+    """False: libm cosf/sinf as the reference calls them. True: correctly rounded, bit-equal to the HIP kernels."""
+    lib().oracle_set_trig_mode(1 if correctly_rounded else 0)
 
 
 def rng_floats(seq, n):
