@@ -36,15 +36,23 @@ RT_DEV void surface_at(const DevScene &sc, int prim, float b0, float b1, float b
     s.light = __float_as_int(s4.y);
 }
 
+// At most two lobes (glass: specular reflection + specular transmission). Scalars, not arrays: runtime-indexed
+// private arrays would be moved to LDS or scratch by the compiler.
 struct DBsdf {
     f3 ns, ss, ts;
     float eta;
     int n;
-    int kind[2], type[2];
+    int kind0, kind1, type0, type1;
     f3 R;
     float etaA, etaB;
 };
+RT_DEV int bx_kind(const DBsdf &b, int i) { return i == 0 ? b.kind0 : b.kind1; }
+RT_DEV int bx_type(const DBsdf &b, int i) { return i == 0 ? b.type0 : b.type1; }
 
+// Material sets a kernel can be specialised for (chosen at scene upload).
+enum { MATSET_ANY = 0, MATSET_LAMBERT = 1 };
+
+template <int MATSET>
 RT_DEV void bsdf_init(DBsdf &b, const Surf &s, const DevMaterial &m) {
     b.ns = s.n;
     b.ss = s.ss;
@@ -54,34 +62,34 @@ RT_DEV void bsdf_init(DBsdf &b, const Surf &s, const DevMaterial &m) {
     b.etaA = 1.f;
     b.etaB = 1.f;
     b.n = 0;
-    b.kind[0] = b.kind[1] = 0;
-    b.type[0] = b.type[1] = 0;
+    b.kind0 = b.kind1 = 0;
+    b.type0 = b.type1 = 0;
     if (black3(b.R)) return;
-    if (m.type == RT_MAT_LAMBERTIAN) {
-        b.kind[0] = BX_LAMBERT; b.type[0] = BSDF_REFLECTION | BSDF_DIFFUSE; b.n = 1;
+    if (MATSET == MATSET_LAMBERT || m.type == RT_MAT_LAMBERTIAN) {
+        b.kind0 = BX_LAMBERT; b.type0 = BSDF_REFLECTION | BSDF_DIFFUSE; b.n = 1;
     } else if (m.type == RT_MAT_MIRROR) {
-        b.kind[0] = BX_SPEC_REFL_NOOP; b.type[0] = BSDF_REFLECTION | BSDF_SPECULAR; b.n = 1;
+        b.kind0 = BX_SPEC_REFL_NOOP; b.type0 = BSDF_REFLECTION | BSDF_SPECULAR; b.n = 1;
     } else {
         b.eta = m.eta;
         b.etaB = m.eta;
-        b.kind[0] = BX_SPEC_REFL_DIELECTRIC; b.type[0] = BSDF_REFLECTION | BSDF_SPECULAR;
-        b.kind[1] = BX_SPEC_TRANS; b.type[1] = BSDF_TRANSMISSION | BSDF_SPECULAR;
+        b.kind0 = BX_SPEC_REFL_DIELECTRIC; b.type0 = BSDF_REFLECTION | BSDF_SPECULAR;
+        b.kind1 = BX_SPEC_TRANS; b.type1 = BSDF_TRANSMISSION | BSDF_SPECULAR;
         b.n = 2;
     }
 }
 RT_DEV bool bx_matches(int type, int flags) { return (type & flags) == type; }
 RT_DEV int bsdf_num(const DBsdf &b, int flags) {
     int c = 0;
-    for (int i = 0; i < b.n; ++i) if (bx_matches(b.type[i], flags)) ++c;
+    for (int i = 0; i < b.n; ++i) if (bx_matches(bx_type(b, i), flags)) ++c;
     return c;
 }
 RT_DEV f3 w2l(const DBsdf &b, f3 v) { return mk3(dot3(v, b.ss), dot3(v, b.ts), dot3(v, b.ns)); }
 RT_DEV f3 l2w(const DBsdf &b, f3 v) {
     return mk3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z, b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
 }
-RT_DEV f3 bx_f(const DBsdf &b, int i) { return b.kind[i] == BX_LAMBERT ? b.R * RT_INV_PI : mk3(0.f, 0.f, 0.f); }
+RT_DEV f3 bx_f(const DBsdf &b, int i) { return bx_kind(b, i) == BX_LAMBERT ? b.R * RT_INV_PI : mk3(0.f, 0.f, 0.f); }
 RT_DEV float bx_pdf(const DBsdf &b, int i, f3 wo, f3 wi) {
-    if (b.kind[i] != BX_LAMBERT) return 0.f;
+    if (bx_kind(b, i) != BX_LAMBERT) return 0.f;
     return (wo.z * wi.z > 0) ? fabsf(wi.z) * RT_INV_PI : 0;
 }
 RT_DEV f3 bsdf_f(const DBsdf &b, f3 woW, f3 wiW, int flags) {
@@ -91,7 +99,7 @@ RT_DEV f3 bsdf_f(const DBsdf &b, f3 woW, f3 wiW, int flags) {
     if (wo.z == 0) return r;
     const bool reflect = dot3(wiW, b.ns) * dot3(woW, b.ns) > 0;
     for (int i = 0; i < b.n; ++i)
-        if (bx_matches(b.type[i], flags) && ((reflect && (b.type[i] & BSDF_REFLECTION)) || (!reflect && (b.type[i] & BSDF_TRANSMISSION))))
+        if (bx_matches(bx_type(b, i), flags) && ((reflect && (bx_type(b, i) & BSDF_REFLECTION)) || (!reflect && (bx_type(b, i) & BSDF_TRANSMISSION))))
             r = r + bx_f(b, i);
     return r;
 }
@@ -102,7 +110,7 @@ RT_DEV float bsdf_pdf(const DBsdf &b, f3 woW, f3 wiW, int flags) {
     float p = 0.f;
     int matching = 0;
     for (int i = 0; i < b.n; ++i)
-        if (bx_matches(b.type[i], flags)) { ++matching; p += bx_pdf(b, i, wo, wi); }
+        if (bx_matches(bx_type(b, i), flags)) { ++matching; p += bx_pdf(b, i, wo, wi); }
     return matching > 0 ? p / matching : 0.f;
 }
 
@@ -139,7 +147,7 @@ RT_DEV float fr_dielectric(float cosThetaI, float etaI, float etaT) {
 
 // BxDF::sample_f of lobe i. Returns f; pdf = 0 means failure.
 RT_DEV f3 bx_sample(const DBsdf &b, int i, f3 wo, f3 &wi, float u0, float u1, float &pdf) {
-    const int k = b.kind[i];
+    const int k = bx_kind(b, i);
     if (k == BX_LAMBERT) {
         wi = cosine_hemisphere(u0, u1);
         if (wo.z < 0) wi.z *= -1;
@@ -180,24 +188,24 @@ RT_DEV f3 bsdf_sample(const DBsdf &b, f3 woW, f3 &wiW, float u0, float u1, float
     const int comp = min((int)floorf(u0 * matching), matching - 1);
     int sel = 0, count = comp;
     for (int i = 0; i < b.n; ++i)
-        if (bx_matches(b.type[i], type) && count-- == 0) { sel = i; break; }
+        if (bx_matches(bx_type(b, i), type) && count-- == 0) { sel = i; break; }
     const float ur0 = gmin(u0 * matching - comp, RT_ONE_MINUS_EPS);
     f3 wi, wo = w2l(b, woW);
     if (wo.z == 0) { sampledType = 0; return mk3(0.f, 0.f, 0.f); }
     pdf = 0;
-    sampledType = b.type[sel];
+    sampledType = bx_type(b, sel);
     f3 f = bx_sample(b, sel, wo, wi, ur0, u1, pdf);
     if (pdf == 0) { sampledType = 0; return mk3(0.f, 0.f, 0.f); }
     wiW = l2w(b, wi);
-    if (!(b.type[sel] & BSDF_SPECULAR) && matching > 1)
+    if (!(bx_type(b, sel) & BSDF_SPECULAR) && matching > 1)
         for (int i = 0; i < b.n; ++i)
-            if (i != sel && bx_matches(b.type[i], type)) pdf += bx_pdf(b, i, wo, wi);
+            if (i != sel && bx_matches(bx_type(b, i), type)) pdf += bx_pdf(b, i, wo, wi);
     if (matching > 1) pdf /= matching;
-    if (!(b.type[sel] & BSDF_SPECULAR)) {
+    if (!(bx_type(b, sel) & BSDF_SPECULAR)) {
         const bool reflect = dot3(wiW, b.ns) * dot3(woW, b.ns) > 0;
         f = mk3(0.f, 0.f, 0.f);
         for (int i = 0; i < b.n; ++i)
-            if (bx_matches(b.type[i], type) && ((reflect && (b.type[i] & BSDF_REFLECTION)) || (!reflect && (b.type[i] & BSDF_TRANSMISSION))))
+            if (bx_matches(bx_type(b, i), type) && ((reflect && (bx_type(b, i) & BSDF_REFLECTION)) || (!reflect && (bx_type(b, i) & BSDF_TRANSMISSION))))
                 f = f + bx_f(b, i);
     }
     return f;

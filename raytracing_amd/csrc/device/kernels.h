@@ -112,16 +112,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DevScene sc, uint64_t n,
 //   shadow A = {o.xyz, d.x}  B = {d.y, d.z, bits(pathId), c.r}  C = {c.g, c.b, -, -}
 //   probe   = 6 float4: {p, hasShadow} {shadowDir, pathId} {A, light} {wi, weight} {f|cos|, pdf} {beta, selPdf}
 // Per-path state (indexed by pathId = localSample * nPix + pixel):
-//   L = {rgb, etaScale}   beta = {rgb, -}   rng = PCG32 state (the increment is recomputed from the path id)
+//   L = {rgb, etaScale}   beta = {rgb, -}   rng = PCG32 state and increment
 struct PathBuffers {
     float4 *rayA[2], *rayB[2];
     float4 *hit;
     float4 *L, *beta;
-    uint2 *rng;
+    uint4 *rng;   // PCG32 state (x,y) and increment (z,w)
     float4 *shA, *shB, *shC;
     float4 *probe;
-    uint32_t *counts;   // [(maxDepth + 2)][4]: 0 = rays entering bounce b, 1 = shadow entries, 2 = probe entries
+    uint32_t *counts;   // see cnt_index
 };
+
+// Queue counters: one 128-byte line per counter so that appends to different queues do not serialise on one
+// L2 line. Counter q of bounce b lives at counts[(b * 3 + q) * RT_CNT_STRIDE]; q: 0 = rays entering bounce b,
+// 1 = shadow entries of bounce b, 2 = probe entries of bounce b.
+#define RT_CNT_STRIDE 32
+RT_HD uint32_t cnt_index(int bounce, int q) { return (uint32_t)(bounce * 3 + q) * RT_CNT_STRIDE; }
 
 struct PassInfo {
     uint32_t nPix;         // pixels in the sample bounds
@@ -144,17 +150,33 @@ RT_DEV uint64_t path_sequence(const CameraDev &cam, const PassInfo &ps, uint32_t
     return counter_sequence(pix, ps.sppTotal, ps.sppBase + sLocal, ps.seed);
 }
 
-// Wave-aggregated append: returns this lane's slot when `want`, one atomic per wave.
-RT_DEV uint32_t wave_append(uint32_t *counter, bool want) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0;
-    const uint32_t lane = __lane_id();
-    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    return base + rank;
+// Block-aggregated append to three queues at once: wave ballots give per-wave counts, one lane per queue
+// issues a single atomicAdd for the whole 256-thread block, and every lane gets base + rank. All threads of the
+// block must call it (it synchronises). `lds` holds 16 dwords.
+RT_DEV void block_append3(uint32_t *lds, uint32_t *c0, uint32_t *c1, uint32_t *c2, bool w0, bool w1, bool w2, uint32_t &s0, uint32_t &s1,
+                          uint32_t &s2) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1), m2 = __ballot(w2);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+        lds[0 * 4 + wave] = (uint32_t)__popcll(m0);
+        lds[1 * 4 + wave] = (uint32_t)__popcll(m1);
+        lds[2 * 4 + wave] = (uint32_t)__popcll(m2);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t q = threadIdx.x;
+        const uint32_t total = lds[q * 4 + 0] + lds[q * 4 + 1] + lds[q * 4 + 2] + lds[q * 4 + 3];
+        uint32_t *ctr = q == 0 ? c0 : (q == 1 ? c1 : c2);
+        lds[12 + q] = total ? atomicAdd(ctr, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t pre0 = 0, pre1 = 0, pre2 = 0;
+    for (uint32_t w = 0; w < wave; ++w) { pre0 += lds[0 * 4 + w]; pre1 += lds[1 * 4 + w]; pre2 += lds[2 * 4 + w]; }
+    s0 = lds[12] + pre0 + (uint32_t)__popcll(m0 & below);
+    s1 = lds[13] + pre1 + (uint32_t)__popcll(m1 & below);
+    s2 = lds[14] + pre2 + (uint32_t)__popcll(m2 & below);
+    __syncthreads();   // lds is reused by the next iteration
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_raygen(CameraDev cam, PassInfo ps, PathBuffers pb, unsigned long long *stats) {
@@ -171,10 +193,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(CameraDev cam, PassInfo ps,
         pb.rayB[0][id] = make_float4(d.y, d.z, __uint_as_float(id), 0.f);
         pb.L[id] = make_float4(0.f, 0.f, 0.f, 1.f);
         pb.beta[id] = make_float4(1.f, 1.f, 1.f, 0.f);
-        pb.rng[id] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+        pb.rng[id] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        pb.counts[0] = n;
+        pb.counts[cnt_index(0, 0)] = n;
         atomicAdd(&stats[ST_CAMERA_SAMPLES], (unsigned long long)n);
     }
 }
@@ -209,13 +231,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
 // One bounce of PathRenderer::Li (Render/Render.cpp:363-445) for every live path, after its closest hit
 // is known: emission, light sampling with MIS (uniformSampleOneLight / estimateDirect, :189-312), BSDF
 // sampling, Russian roulette. Visibility is resolved by k_shadow / k_probe afterwards.
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, CameraDev cam, PassInfo ps, PathBuffers pb, int bounce) {
+template <int MATSET>
+__global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev cam, PassInfo ps, PathBuffers pb, int bounce) {
     const int cur = bounce & 1, nxt = cur ^ 1;
-    const uint32_t n = pb.counts[bounce * 4 + 0];
-    uint32_t *cntNext = &pb.counts[(bounce + 1) * 4 + 0];
-    uint32_t *cntShadow = &pb.counts[bounce * 4 + 1];
-    uint32_t *cntProbe = &pb.counts[bounce * 4 + 2];
-    const uint32_t nRound = (n + 63u) & ~63u;   // whole waves enter the loop so ballots see every lane
+    __shared__ uint32_t s_app[16];
+    const uint32_t n = pb.counts[cnt_index(bounce, 0)];
+    uint32_t *cntNext = &pb.counts[cnt_index(bounce + 1, 0)];
+    uint32_t *cntShadow = &pb.counts[cnt_index(bounce, 1)];
+    uint32_t *cntProbe = &pb.counts[cnt_index(bounce, 2)];
+    const uint32_t nRound = (n + RT_BLOCK - 1u) & ~(RT_BLOCK - 1u);   // whole blocks enter the loop: the append synchronises
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < nRound; i += gridDim.x * RT_BLOCK) {
         bool alive = i < n;
         bool wantShadow = false, wantProbe = false;
@@ -250,13 +274,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, CameraDev cam, 
                 }
                 if (bounce < ps.maxDepth) {
                     DBsdf bs;
-                    bsdf_init(bs, sf, sc.mats[sf.mat]);
-                    int px, py;
-                    uint32_t sLocal;
+                    bsdf_init<MATSET>(bs, sf, sc.mats[sf.mat]);
                     Pcg rng;
-                    rng.inc = (path_sequence(cam, ps, pathId, px, py, sLocal) << 1u) | 1u;
-                    const uint2 st = pb.rng[pathId];
+                    const uint4 st = pb.rng[pathId];
                     rng.state = (uint64_t)st.x | ((uint64_t)st.y << 32);
+                    rng.inc = (uint64_t)st.z | ((uint64_t)st.w << 32);
                     const f3 isectWo = normalize3(-rd);
 
                     if (bsdf_num(bs, BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.nLights > 0) {
@@ -351,7 +373,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, CameraDev cam, 
                                 nA = make_float4(sf.p.x, sf.p.y, sf.p.z, nd.x);
                                 nB = make_float4(nd.y, nd.z, __uint_as_float(pathId | (spec ? 0x80000000u : 0u)), 0.f);
                                 pb.beta[pathId] = make_float4(beta.x, beta.y, beta.z, 0.f);
-                                pb.rng[pathId] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                                pb.rng[pathId] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), st.z, st.w);
                                 if (etaScale != L4.w) { L4.w = etaScale; Ldirty = true; }
                             }
                         }
@@ -360,11 +382,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, CameraDev cam, 
                 if (Ldirty) pb.L[pathId] = L4;
             }
         }
-        const uint32_t slotN = wave_append(cntNext, alive);
+        uint32_t slotN, slotS, slotP;
+        block_append3(s_app, cntNext, cntShadow, cntProbe, alive, wantShadow, wantProbe, slotN, slotS, slotP);
         if (alive) { pb.rayA[nxt][slotN] = nA; pb.rayB[nxt][slotN] = nB; }
-        const uint32_t slotS = wave_append(cntShadow, wantShadow);
         if (wantShadow) { pb.shA[slotS] = sA; pb.shB[slotS] = sB; pb.shC[slotS] = sC; }
-        const uint32_t slotP = wave_append(cntProbe, wantProbe);
         if (wantProbe) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) pb.probe[(size_t)slotP * 6 + k] = pr[k];
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, CameraDev cam, 
 template <bool LDS_SCENE, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
     extern __shared__ uint4 smem[];
-    const uint32_t n = pb.counts[bounce * 4 + 1];
+    const uint32_t n = pb.counts[cnt_index(bounce, 1)];
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb
 template <bool LDS_SCENE, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
     extern __shared__ uint4 smem[];
-    const uint32_t n = pb.counts[bounce * 4 + 2];
+    const uint32_t n = pb.counts[cnt_index(bounce, 2)];
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
@@ -571,7 +592,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
                 surface_at(sc, h.prim, h.b0, h.b1, h.b2, sf);
                 const f3 wo = normalize3(-rdir);
                 DBsdf bs;
-                bsdf_init(bs, sf, sc.mats[sf.mat]);
+                bsdf_init<MATSET_ANY>(bs, sf, sc.mats[sf.mat]);
                 f3 L = mk3(0.f, 0.f, 0.f);
                 if (!countOnly && sf.light >= 0) L = L + light_L(sc.lights[sf.light], sf.n, wo);
                 for (uint32_t li = 0; li < sc.nLights; ++li) {
@@ -615,7 +636,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
             Surf sf;
             surface_at(sc, f.prim, f.b0, f.b1, f.b2, sf);
             DBsdf bs;
-            bsdf_init(bs, sf, sc.mats[sf.mat]);
+            bsdf_init<MATSET_ANY>(bs, sf, sc.mats[sf.mat]);
             const f3 wo = normalize3(-f.rd);
             const int type = (f.stage == 0 ? BSDF_REFLECTION : BSDF_TRANSMISSION) | BSDF_SPECULAR;
             f.stage += 1;

@@ -35,6 +35,7 @@ struct rt_context {
     void *dLightCdf = nullptr, *dLightFunc = nullptr;
     bool ldsScene = false;
     bool hasGlass = false;
+    bool allLambert = false;
 
     // camera
     bool haveCamera = false;
@@ -168,12 +169,12 @@ int ensure_path_buffers(rt_context *c, size_t nPaths, int maxDepth) {
     if ((rc = alloc((void **)&pb.hit, nPaths * 16))) return rc;
     if ((rc = alloc((void **)&pb.L, nPaths * 16))) return rc;
     if ((rc = alloc((void **)&pb.beta, nPaths * 16))) return rc;
-    if ((rc = alloc((void **)&pb.rng, nPaths * 8))) return rc;
+    if ((rc = alloc((void **)&pb.rng, nPaths * 16))) return rc;
     if ((rc = alloc((void **)&pb.shA, nPaths * 16))) return rc;
     if ((rc = alloc((void **)&pb.shB, nPaths * 16))) return rc;
     if ((rc = alloc((void **)&pb.shC, nPaths * 16))) return rc;
     if ((rc = alloc((void **)&pb.probe, nPaths * 16 * 6))) return rc;
-    if ((rc = alloc((void **)&pb.counts, (size_t)(maxDepth + 2) * 4 * sizeof(uint32_t)))) return rc;
+    if ((rc = alloc((void **)&pb.counts, (size_t)(maxDepth + 2) * 3 * RT_CNT_STRIDE * sizeof(uint32_t)))) return rc;
     c->pbCapacity = nPaths;
     c->pbDepth = maxDepth;
     return RT_OK;
@@ -265,7 +266,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
         ps.seed = p->seed;
         ps.maxDepth = p->max_depth;
         ps.rrThreshold = p->rr_threshold;
-        HIPCHK(c, hipMemsetAsync(pb.counts, 0, (size_t)(p->max_depth + 2) * 4 * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(pb.counts, 0, (size_t)(p->max_depth + 2) * 3 * RT_CNT_STRIDE * sizeof(uint32_t), c->stream));
         hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, c->stream, cam, ps, pb, c->dStats);
         for (int b = 0; b <= p->max_depth; ++b) {
             const int cur = b & 1;
@@ -274,10 +275,11 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
             {
                 auto k = c->ldsScene ? (stats ? k_extend<true, true> : k_extend<true, false>) : (stats ? k_extend<false, true> : k_extend<false, false>);
                 hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, (const float4 *)pb.rayA[cur], (const float4 *)pb.rayB[cur],
-                                   pb.hit, (const uint32_t *)&pb.counts[b * 4], c->dStats);
+                                   pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
             }
             if (ep) HIPCHK(c, hipEventRecord(ep->b, c->stream));
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->sc, cam, ps, pb, b);
+            hipLaunchKernelGGL(c->allLambert ? k_shade<MATSET_LAMBERT> : k_shade<MATSET_ANY>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->sc, cam,
+                               ps, pb, b);
             if (b < p->max_depth) {
                 auto ks = c->ldsScene ? (stats ? k_shadow<true, true> : k_shadow<true, false>) : (stats ? k_shadow<false, true> : k_shadow<false, false>);
                 hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, pb, b, c->dStats);
@@ -438,7 +440,9 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     }
     std::vector<DevMaterial> mats(d->n_materials);
     c->hasGlass = false;
+    c->allLambert = true;
     for (uint32_t i = 0; i < d->n_materials; ++i) {
+        if (d->materials[i].type != RT_MAT_LAMBERTIAN) c->allLambert = false;
         mats[i] = DevMaterial{d->materials[i].rgb[0], d->materials[i].rgb[1], d->materials[i].rgb[2], d->materials[i].eta, d->materials[i].type, 0, 0, 0};
         if (d->materials[i].type == RT_MAT_GLASS) c->hasGlass = true;
     }
