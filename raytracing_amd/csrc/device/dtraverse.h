@@ -12,8 +12,16 @@
 #include "dmath.h"
 
 #define RT_BLOCK 256
-#define RT_STACK_LDS 8        // todo entries per lane kept in LDS
-#define RT_STACK_PRIV 56      // remaining entries (the reference's todo[64])
+#define RT_STACK_TOTAL 64     // the reference's todo[64]
+// todo entries per lane kept in LDS; the rest lives in private memory. Small (LDS-resident) scenes have
+// shallow trees, so a short LDS part keeps more workgroups resident per CU.
+#ifndef RT_STACK_LDS_SMALL
+#define RT_STACK_LDS_SMALL 4
+#endif
+#ifndef RT_STACK_LDS_LARGE
+#define RT_STACK_LDS_LARGE 8
+#endif
+template <bool LDS_SCENE> struct StackCfg { static constexpr int LDS_N = LDS_SCENE ? RT_STACK_LDS_SMALL : RT_STACK_LDS_LARGE; };
 
 struct DevMaterial {
     float r, g, b, eta;
@@ -160,16 +168,9 @@ struct SceneTables {
     const float4 *triHot;
 };
 
-// Stack access: entry e of lane `tid` lives at stk[(e * 3 + k) * RT_BLOCK + tid] so that lanes at the
-// same depth hit consecutive banks.
-struct TodoStack {
-    uint32_t *lds;
-    uint32_t tid;
-    uint32_t privNode[RT_STACK_PRIV];
-    float privTMin[RT_STACK_PRIV], privTMax[RT_STACK_PRIV];
-};
-
-template <bool CLOSEST, bool STATS>
+// Stack layout: entry e of lane `tid` lives at stk[(e * 3 + k) * RT_BLOCK + tid] so that lanes at the same depth
+// hit consecutive banks.
+template <bool CLOSEST, bool STATS, int SL>
 RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsStack, uint32_t tid, const RayCtx &r, float rayTMaxIn,
                      HitRec &hit, TravCounters &cn) {
     float tMin, tMax;
@@ -179,8 +180,8 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
     hit.b0 = hit.b1 = hit.b2 = 0.f;
     if (!bounds_clip(sc, r, rayTMax, tMin, tMax)) return false;
 
-    uint32_t privNode[RT_STACK_PRIV];
-    float privTMin[RT_STACK_PRIV], privTMax[RT_STACK_PRIV];
+    uint32_t privNode[RT_STACK_TOTAL - SL];
+    float privTMin[RT_STACK_TOTAL - SL], privTMax[RT_STACK_TOTAL - SL];
     int sp = 0;
     uint32_t node = 0;
     bool found = false;
@@ -202,12 +203,12 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
             } else if (tPlane < tMin) {
                 node = second;
             } else {
-                if (sp < RT_STACK_LDS) {
+                if (sp < SL) {
                     ldsStack[(sp * 3 + 0) * RT_BLOCK + tid] = second;
                     ldsStack[(sp * 3 + 1) * RT_BLOCK + tid] = __float_as_uint(tPlane);
                     ldsStack[(sp * 3 + 2) * RT_BLOCK + tid] = __float_as_uint(tMax);
                 } else {
-                    const int q = sp - RT_STACK_LDS;
+                    const int q = sp - SL;
                     privNode[q] = second;
                     privTMin[q] = tPlane;
                     privTMax[q] = tMax;
@@ -246,12 +247,12 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
         }
         if (sp == 0) break;
         --sp;
-        if (sp < RT_STACK_LDS) {
+        if (sp < SL) {
             node = ldsStack[(sp * 3 + 0) * RT_BLOCK + tid];
             tMin = __uint_as_float(ldsStack[(sp * 3 + 1) * RT_BLOCK + tid]);
             tMax = __uint_as_float(ldsStack[(sp * 3 + 2) * RT_BLOCK + tid]);
         } else {
-            const int q = sp - RT_STACK_LDS;
+            const int q = sp - SL;
             node = privNode[q];
             tMin = privTMin[q];
             tMax = privTMax[q];

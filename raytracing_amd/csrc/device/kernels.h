@@ -41,13 +41,13 @@ RT_DEV void flush_counters(unsigned long long *stats, const TravCounters &cn, ui
     atomicAdd(&stats[ST_COUNTED_RAYS], (unsigned long long)rays);
 }
 
-// Dynamic LDS layout of every tracing kernel: [todo stack: RT_STACK_LDS*3*RT_BLOCK dwords][scene tables]
-#define RT_STACK_LDS_BYTES (RT_STACK_LDS * 3 * RT_BLOCK * 4)
+// Dynamic LDS layout of every tracing kernel: [todo stack: LDS_N*3*RT_BLOCK dwords][scene tables]
+template <bool LDS_SCENE> RT_HD constexpr uint32_t stack_lds_bytes() { return StackCfg<LDS_SCENE>::LDS_N * 3 * RT_BLOCK * 4; }
 
 template <bool LDS_SCENE>
 RT_DEV void tables_setup(const DevScene &sc, uint4 *smem, SceneTables &tb) {
     if (LDS_SCENE) {
-        stage_scene_lds(sc, smem + RT_STACK_LDS_BYTES / 16, tb);
+        stage_scene_lds(sc, smem + stack_lds_bytes<LDS_SCENE>() / 16, tb);
     } else {
         tb.nodes = sc.nodes;
         tb.leafIdx = sc.leafIdx;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_
         RayCtx r;
         ray_setup(r, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
         HitRec h;
-        kd_trace<true, STATS>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
+        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
         if (prim) prim[i] = h.prim;
         if (tOut) tOut[i] = h.t;
         if (bary) { bary[3 * i] = h.b0; bary[3 * i + 1] = h.b1; bary[3 * i + 2] = h.b2; }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DevScene sc, uint64_t n,
         RayCtx r;
         ray_setup(r, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
         HitRec h;
-        const bool hit = kd_trace<false, STATS>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
+        const bool hit = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
         occluded[i] = hit ? 1 : 0;
         ++myRays;
     }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
         RayCtx r;
         ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
         HitRec h;
-        kd_trace<true, STATS>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
         hit[i] = make_float4(__int_as_float(h.prim), h.b0, h.b1, h.b2);
         ++myRays;
     }
@@ -396,21 +396,16 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
 // Shadow rays of the light-sampling half (VisibilityTester::unoccluded, Render/Light.cpp:28-31): any-hit
 // over Ray(p, pLight - p, 1 - ShadowEpsilon); a visible light adds its contribution to the path's L.
 template <bool LDS_SCENE, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
-    const uint32_t n = pb.counts[cnt_index(bounce, 1)];
-    if (blockIdx.x * RT_BLOCK >= n) return;
-    SceneTables tb;
-    tables_setup<LDS_SCENE>(sc, smem, tb);
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+RT_DEV void shadow_entries(const DevScene &sc, const SceneTables &tb, uint32_t *stk, const PathBuffers &pb, uint32_t n, uint32_t block,
+                           uint32_t nBlocks, unsigned long long *stats) {
     TravCounters cn = {0, 0, 0, 0};
     uint32_t myRays = 0;
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+    for (uint32_t i = block * RT_BLOCK + threadIdx.x; i < n; i += nBlocks * RT_BLOCK) {
         const float4 a = pb.shA[i], b = pb.shB[i], c = pb.shC[i];
         RayCtx r;
         ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
         HitRec h;
-        const bool occluded = kd_trace<false, STATS>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
+        const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
         if (!occluded) {
             const uint32_t pathId = __float_as_uint(b.z);
             float4 L4 = pb.L[pathId];
@@ -420,23 +415,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb
         ++myRays;
     }
     if (STATS) flush_counters(stats, cn, myRays);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
+    if (block == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }
 
 // Paths whose BSDF sample may see the chosen light (estimateDirect, Render/Render.cpp:266-310): resolve the
 // shadow ray of the light sample (if any) and the closest hit along the BSDF sample, then add
 // beta * ((A' + B') / selPdf) to the path's L with the reference's association.
 template <bool LDS_SCENE, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
-    const uint32_t n = pb.counts[cnt_index(bounce, 2)];
-    if (blockIdx.x * RT_BLOCK >= n) return;
-    SceneTables tb;
-    tables_setup<LDS_SCENE>(sc, smem, tb);
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+RT_DEV void probe_entries(const DevScene &sc, const SceneTables &tb, uint32_t *stk, const PathBuffers &pb, uint32_t n, uint32_t block,
+                          uint32_t nBlocks, unsigned long long *stats) {
     TravCounters cn = {0, 0, 0, 0};
     uint32_t myRays = 0, nShadow = 0;
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+    for (uint32_t i = block * RT_BLOCK + threadIdx.x; i < n; i += nBlocks * RT_BLOCK) {
         const float4 e0 = pb.probe[(size_t)i * 6 + 0], e1 = pb.probe[(size_t)i * 6 + 1], e2 = pb.probe[(size_t)i * 6 + 2];
         const float4 e3 = pb.probe[(size_t)i * 6 + 3], e4 = pb.probe[(size_t)i * 6 + 4], e5 = pb.probe[(size_t)i * 6 + 5];
         const f3 p = mk3(e0.x, e0.y, e0.z);
@@ -447,7 +437,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb,
             RayCtx r;
             ray_setup(r, p, mk3(e1.x, e1.y, e1.z));
             HitRec h;
-            const bool occluded = kd_trace<false, STATS>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
+            const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
             if (!occluded) Ld = Ld + mk3(e2.x, e2.y, e2.z);
             ++myRays;
             ++nShadow;
@@ -457,7 +447,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb,
             RayCtx r;
             ray_setup(r, p, normalize3(wi));
             HitRec h;
-            const bool found = kd_trace<true, STATS>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+            const bool found = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
             ++myRays;
             f3 Li = mk3(0.f, 0.f, 0.f);
             if (found) {
@@ -474,7 +464,27 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb,
     }
     if (STATS) flush_counters(stats, cn, myRays);
     if (nShadow) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)nShadow);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+    if (block == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+}
+
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    const uint32_t n = pb.counts[cnt_index(bounce, 1)];
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    shadow_entries<LDS_SCENE, STATS>(sc, tb, reinterpret_cast<uint32_t *>(smem), pb, n, blockIdx.x, gridDim.x, stats);
+}
+
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    const uint32_t n = pb.counts[cnt_index(bounce, 2)];
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    probe_entries<LDS_SCENE, STATS>(sc, tb, reinterpret_cast<uint32_t *>(smem), pb, n, blockIdx.x, gridDim.x, stats);
 }
 
 // Sample filter of the render loop (Render/Render.cpp:72-83).
@@ -570,7 +580,7 @@ struct WFrame {
 // (L += f * Li(child) * |wi.n| / pdf). The frame at stack position k is the call at recursion depth k.
 // When `countOnly` is set nothing is shaded: the function only consumes the random numbers the full
 // evaluation would consume (the specular tree does not depend on them).
-template <bool STATS>
+template <bool LDS_SCENE, bool STATS>
 RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f3 ro, f3 rdir, Pcg &rng, int maxDepth, bool countOnly,
                      TravCounters &cn, uint32_t &nClosest, uint32_t &nAny) {
     WFrame fr[RT_WHITTED_MAX_FRAMES];
@@ -584,7 +594,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
             ray_setup(r, ro, rdir);
             HitRec h;
             ++nClosest;
-            const bool hit = kd_trace<true, STATS>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+            const bool hit = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
             Lret = mk3(0.f, 0.f, 0.f);
             state = RETURN;
             if (hit) {
@@ -608,7 +618,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
                         ray_setup(sr, sf.p, normalize3(pShape - sf.p));
                         HitRec sh;
                         ++nAny;
-                        if (!kd_trace<false, STATS>(sc, tb, stk, threadIdx.x, sr, 1 - RT_SHADOW_EPS, sh, cn))
+                        if (!kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, sr, 1 - RT_SHADOW_EPS, sh, cn))
                             L = L + f * Li * absdot3(wi, sf.n) / pdf;
                     }
                 }
@@ -689,7 +699,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted_prepass(DevScene sc, Camer
                 const float u0 = pcg_float(rng), u1 = pcg_float(rng);
                 f3 o, d;
                 camera_ray(cam, (float)x + u0, (float)y + u1, o, d);
-                whitted_li<false>(sc, tb, stk, o, d, rng, maxDepth, true, cn, nc, na);
+                whitted_li<LDS_SCENE, false>(sc, tb, stk, o, d, rng, maxDepth, true, cn, nc, na);
             }
         }
 }
@@ -732,7 +742,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam
             const float pfx = (float)px + u0, pfy = (float)py + u1;
             f3 o, d;
             camera_ray(cam, pfx, pfy, o, d);
-            f3 L = whitted_li<STATS>(sc, tb, stk, o, d, rng, maxDepth, false, cn, nc, na);
+            f3 L = whitted_li<LDS_SCENE, STATS>(sc, tb, stk, o, d, rng, maxDepth, false, cn, nc, na);
             L = sanitize_L(L);
             ++ns;
             int fx0, fy0, fx1, fy1;

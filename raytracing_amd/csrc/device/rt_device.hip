@@ -47,8 +47,13 @@ struct rt_context {
     size_t extendEventsUsed = 0;
     double renderMs = 0;
 
-    // path buffers
-    PathBuffers pb{};
+    // path tracer pipelines: consecutive passes alternate between two sets of buffers on two streams, so the
+    // small late-bounce launches of one pass overlap the large early-bounce launches of the next
+    static constexpr int kPipes = 2;
+    PathBuffers pb[kPipes]{};
+    hipStream_t pipeStream[kPipes] = {nullptr, nullptr};
+    hipEvent_t pipeFilmDone[kPipes] = {nullptr, nullptr};
+    hipEvent_t mainReady = nullptr;
     size_t pbCapacity = 0;
     int pbDepth = 0;
     std::vector<void *> pbAllocs;
@@ -90,7 +95,7 @@ void free_path_buffers(rt_context *c) {
     c->pbAllocs.clear();
     c->pbCapacity = 0;
     c->pbDepth = 0;
-    c->pb = PathBuffers{};
+    for (auto &pb : c->pb) pb = PathBuffers{};
 }
 
 // Per-triangle constants of the surface part of ATriangleShape::hit (reference
@@ -136,7 +141,7 @@ int upload(rt_context *c, void **dst, const std::vector<T> &v, size_t padBytes =
     return RT_OK;
 }
 
-size_t trace_lds_bytes(const rt_context *c) { return RT_STACK_LDS_BYTES + (c->ldsScene ? c->sc.ldsSceneBytes : 0); }
+size_t trace_lds_bytes(const rt_context *c) { return c->ldsScene ? stack_lds_bytes<true>() + c->sc.ldsSceneBytes : stack_lds_bytes<false>(); }
 
 int ensure_spill(rt_context *c) {
     const size_t n = (size_t)c->cam.width * c->cam.height;
@@ -161,20 +166,22 @@ int ensure_path_buffers(rt_context *c, size_t nPaths, int maxDepth) {
         return RT_OK;
     };
     int rc;
-    PathBuffers &pb = c->pb;
-    for (int q = 0; q < 2; ++q) {
-        if ((rc = alloc((void **)&pb.rayA[q], nPaths * 16))) return rc;
-        if ((rc = alloc((void **)&pb.rayB[q], nPaths * 16))) return rc;
+    for (int k = 0; k < rt_context::kPipes; ++k) {
+        PathBuffers &pb = c->pb[k];
+        for (int q = 0; q < 2; ++q) {
+            if ((rc = alloc((void **)&pb.rayA[q], nPaths * 16))) return rc;
+            if ((rc = alloc((void **)&pb.rayB[q], nPaths * 16))) return rc;
+        }
+        if ((rc = alloc((void **)&pb.hit, nPaths * 16))) return rc;
+        if ((rc = alloc((void **)&pb.L, nPaths * 16))) return rc;
+        if ((rc = alloc((void **)&pb.beta, nPaths * 16))) return rc;
+        if ((rc = alloc((void **)&pb.rng, nPaths * 16))) return rc;
+        if ((rc = alloc((void **)&pb.shA, nPaths * 16))) return rc;
+        if ((rc = alloc((void **)&pb.shB, nPaths * 16))) return rc;
+        if ((rc = alloc((void **)&pb.shC, nPaths * 16))) return rc;
+        if ((rc = alloc((void **)&pb.probe, nPaths * 16 * 6))) return rc;
+        if ((rc = alloc((void **)&pb.counts, (size_t)(maxDepth + 2) * 3 * RT_CNT_STRIDE * sizeof(uint32_t)))) return rc;
     }
-    if ((rc = alloc((void **)&pb.hit, nPaths * 16))) return rc;
-    if ((rc = alloc((void **)&pb.L, nPaths * 16))) return rc;
-    if ((rc = alloc((void **)&pb.beta, nPaths * 16))) return rc;
-    if ((rc = alloc((void **)&pb.rng, nPaths * 16))) return rc;
-    if ((rc = alloc((void **)&pb.shA, nPaths * 16))) return rc;
-    if ((rc = alloc((void **)&pb.shB, nPaths * 16))) return rc;
-    if ((rc = alloc((void **)&pb.shC, nPaths * 16))) return rc;
-    if ((rc = alloc((void **)&pb.probe, nPaths * 16 * 6))) return rc;
-    if ((rc = alloc((void **)&pb.counts, (size_t)(maxDepth + 2) * 3 * RT_CNT_STRIDE * sizeof(uint32_t)))) return rc;
     c->pbCapacity = nPaths;
     c->pbDepth = maxDepth;
     return RT_OK;
@@ -254,9 +261,16 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     const bool stats = p->collect_stats != 0;
     const size_t lds = trace_lds_bytes(c);
     const int grid = c->gridBlocks;
-    PathBuffers &pb = c->pb;
 
-    for (int s0 = p->spp_begin; s0 < p->spp_end; s0 += sppPass) {
+    // the pipelines start after everything already queued on the context's stream
+    HIPCHK(c, hipEventRecord(c->mainReady, c->stream));
+    for (int k = 0; k < rt_context::kPipes; ++k) HIPCHK(c, hipStreamWaitEvent(c->pipeStream[k], c->mainReady, 0));
+    int lastPipe = -1;
+    int passIndex = 0;
+    for (int s0 = p->spp_begin; s0 < p->spp_end; s0 += sppPass, ++passIndex) {
+        const int k = passIndex % rt_context::kPipes;
+        PathBuffers &pb = c->pb[k];
+        hipStream_t st = c->pipeStream[k];
         PassInfo ps;
         ps.nPix = (uint32_t)nPix;
         ps.sbW = sbW;
@@ -266,29 +280,37 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
         ps.seed = p->seed;
         ps.maxDepth = p->max_depth;
         ps.rrThreshold = p->rr_threshold;
-        HIPCHK(c, hipMemsetAsync(pb.counts, 0, (size_t)(p->max_depth + 2) * 3 * RT_CNT_STRIDE * sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, c->stream, cam, ps, pb, c->dStats);
+        HIPCHK(c, hipMemsetAsync(pb.counts, 0, (size_t)(p->max_depth + 2) * 3 * RT_CNT_STRIDE * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cam, ps, pb, c->dStats);
         for (int b = 0; b <= p->max_depth; ++b) {
             const int cur = b & 1;
             EventPair *ep = next_event_pair(c);
-            if (ep) HIPCHK(c, hipEventRecord(ep->a, c->stream));
+            if (ep) HIPCHK(c, hipEventRecord(ep->a, st));
             {
-                auto k = c->ldsScene ? (stats ? k_extend<true, true> : k_extend<true, false>) : (stats ? k_extend<false, true> : k_extend<false, false>);
-                hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, (const float4 *)pb.rayA[cur], (const float4 *)pb.rayB[cur],
-                                   pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
+                auto kx = c->ldsScene ? (stats ? k_extend<true, true> : k_extend<true, false>) : (stats ? k_extend<false, true> : k_extend<false, false>);
+                hipLaunchKernelGGL(kx, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, (const float4 *)pb.rayA[cur], (const float4 *)pb.rayB[cur], pb.hit,
+                                   (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
             }
-            if (ep) HIPCHK(c, hipEventRecord(ep->b, c->stream));
-            hipLaunchKernelGGL(c->allLambert ? k_shade<MATSET_LAMBERT> : k_shade<MATSET_ANY>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->sc, cam,
-                               ps, pb, b);
+            if (ep) HIPCHK(c, hipEventRecord(ep->b, st));
+            hipLaunchKernelGGL(c->allLambert ? k_shade<MATSET_LAMBERT> : k_shade<MATSET_ANY>, dim3(grid), dim3(RT_BLOCK), 0, st, c->sc, cam, ps, pb, b);
             if (b < p->max_depth) {
                 auto ks = c->ldsScene ? (stats ? k_shadow<true, true> : k_shadow<true, false>) : (stats ? k_shadow<false, true> : k_shadow<false, false>);
-                hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, pb, b, c->dStats);
+                hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
                 auto kp = c->ldsScene ? (stats ? k_probe<true, true> : k_probe<true, false>) : (stats ? k_probe<false, true> : k_probe<false, false>);
-                hipLaunchKernelGGL(kp, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, pb, b, c->dStats);
+                hipLaunchKernelGGL(kp, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
             }
         }
-        hipLaunchKernelGGL(k_film_path, dim3(grid), dim3(RT_BLOCK), 0, c->stream, cam, ps, pb, rgb, wsum, c->dSpillRgb, c->dSpillW);
+        // film accumulation is ordered across passes: pass i+1 adds its samples after pass i
+        if (lastPipe >= 0 && lastPipe != k) HIPCHK(c, hipStreamWaitEvent(st, c->pipeFilmDone[lastPipe], 0));
+        hipLaunchKernelGGL(k_film_path, dim3(grid), dim3(RT_BLOCK), 0, st, cam, ps, pb, rgb, wsum, c->dSpillRgb, c->dSpillW);
+        HIPCHK(c, hipEventRecord(c->pipeFilmDone[k], st));
+        lastPipe = k;
         HIPCHK(c, hipGetLastError());
+    }
+    // join: the context's stream continues after both pipelines
+    for (int k = 0; k < rt_context::kPipes; ++k) {
+        HIPCHK(c, hipEventRecord(c->mainReady, c->pipeStream[k]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->mainReady, 0));
     }
     hipLaunchKernelGGL(k_merge_spill, dim3(grid), dim3(RT_BLOCK), 0, c->stream, (size_t)cam.width * cam.height, rgb, wsum, c->dSpillRgb, c->dSpillW);
     HIPCHK(c, hipGetLastError());
@@ -363,6 +385,11 @@ int rt_create(int device_id, rt_context **out) {
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->gridBlocks = c->numCUs * 8;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (int k = 0; k < rt_context::kPipes; ++k) {
+        if ((e = hipStreamCreateWithFlags(&c->pipeStream[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&c->pipeFilmDone[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    }
+    if ((e = hipEventCreateWithFlags(&c->mainReady, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&c->dStats, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->dStats, 0, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     *out = c;
@@ -373,6 +400,11 @@ void rt_destroy(rt_context *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < rt_context::kPipes; ++k) {
+        if (c->pipeStream[k]) { (void)hipStreamSynchronize(c->pipeStream[k]); (void)hipStreamDestroy(c->pipeStream[k]); }
+        if (c->pipeFilmDone[k]) (void)hipEventDestroy(c->pipeFilmDone[k]);
+    }
+    if (c->mainReady) (void)hipEventDestroy(c->mainReady);
     free_scene(c);
     free_path_buffers(c);
     if (c->dStats) (void)hipFree(c->dStats);
