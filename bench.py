@@ -132,6 +132,7 @@ def main():
     t0 = time.perf_counter()
     run(rank * K * P, (rank + 1) * K * P, spp_total)
     if world > 1:
+        ctx.synchronize()   # the render runs on the library's own streams; RCCL runs on torch's
         dist.reduce(rgb, dst=0, op=dist.ReduceOp.SUM)
         dist.reduce(wsum, dst=0, op=dist.ReduceOp.SUM)
     fence()

@@ -51,8 +51,8 @@ struct rt_context {
     // small late-bounce launches of one pass overlap the large early-bounce launches of the next
     static constexpr int kPipes = 2;
     PathBuffers pb[kPipes]{};
-    hipStream_t pipeStream[kPipes] = {nullptr, nullptr};
-    hipEvent_t pipeFilmDone[kPipes] = {nullptr, nullptr};
+    hipStream_t pipeStream[kPipes] = {};
+    hipEvent_t pipeFilmDone[kPipes] = {};
     hipEvent_t mainReady = nullptr;
     size_t pbCapacity = 0;
     int pbDepth = 0;
