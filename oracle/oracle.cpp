@@ -20,7 +20,7 @@
  * compiled in this build's environment without its vendored cmake projects (glog, assimp), so the
  * oracle is pinned by the artefacts the reference does hold and publish: the 800x800 512-spp
  * cornellBox.png (tests compare an oracle render against it) and the KD-tree / traversal statistics
- * of the reference recorded by the survey. Results that depend on libm's cosf/sinf are "parity unpinned".
+ * measured once on the compiled reference. Results that depend on libm's cosf/sinf are "parity unpinned".
  */
 #include <algorithm>
 #include <atomic>

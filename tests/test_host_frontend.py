@@ -1,7 +1,7 @@
 """Host front-end (scene JSON + OBJ import, SAH KD build, camera, film) against known answers.
 
-Known answers marked [survey] were measured on the reference itself when it was compiled for the survey of this
-build (tree shape and traversal statistics of its KdTree on the shipped cornellBox scene)."""
+Known answers marked [measured on the reference] were obtained from the reference itself, compiled and run once
+(tree shape and traversal statistics of its KdTree on the shipped cornellBox scene)."""
 import os
 
 import numpy as np
@@ -27,11 +27,11 @@ def test_loader_reproduces_committed_fixture(path_scene):
 @needs_reference
 def test_kd_tree_shape_matches_reference():
     s = load_scene_json(REF_SCENE)
-    # [survey] 38 hitables, 2 lights, 133 nodes (67 leaves, 5 empty, max 10 prims/leaf, 322 prim refs)
+    # [measured on the reference] 38 hitables, 2 lights, 133 nodes (67 leaves, 5 empty, max 10 prims/leaf, 322 prim refs)
     assert s.n_prims == 38 and len(s.lights) == 2
     assert s.tree_stats == dict(n_nodes=133, n_leaves=67, n_empty_leaves=5, max_leaf_prims=10, n_prim_refs=322,
                                 n_leaf_idx=322, max_depth_param=15)
-    # [survey] bounds (0,0,0)-(556,548.8,559.2)
+    # [measured on the reference] bounds (0,0,0)-(556,548.8,559.2)
     np.testing.assert_allclose(s.bounds, [0, 0, 0, 556, 548.8, 559.2], rtol=1e-6)
 
 

@@ -1,8 +1,8 @@
 """Pins the CPU oracle to what is known about the reference.
 
 The reference ships no tests and no golden vectors. What it does hold is its published 800x800 / 512 spp
-cornellBox.png, and the survey of this build measured, on the compiled reference, KD-tree and traversal statistics.
-The oracle must reproduce all of them. [survey] marks those measured numbers."""
+cornellBox.png; in addition KD-tree and traversal statistics were measured once on the compiled reference itself.
+The oracle must reproduce all of them. [measured on the reference] marks those numbers."""
 import numpy as np
 import pytest
 
@@ -40,7 +40,7 @@ def test_pcg32_streams():
 
 
 def test_primary_ray_traversal_statistics(path_scene):
-    """[survey] primary rays, cornellBox 800x800, 160 000 rays: 7.23 interior + 2.40 leaf nodes and 8.58 triangle
+    """[measured on the reference] primary rays, cornellBox 800x800, 160 000 rays: 7.23 interior + 2.40 leaf nodes and 8.58 triangle
     tests per ray, maximum todo depth 4."""
     orc = Oracle(path_scene)
     xs, ys = np.meshgrid(np.arange(0, 800, 2) + 0.5, np.arange(0, 800, 2) + 0.5)
@@ -55,7 +55,7 @@ def test_primary_ray_traversal_statistics(path_scene):
 
 
 def test_incoherent_ray_traversal_statistics(path_scene):
-    """[survey] incoherent rays (origins uniform in the bounds, directions uniform on the sphere):
+    """[measured on the reference] incoherent rays (origins uniform in the bounds, directions uniform on the sphere):
     7.98 interior + 2.33 leaves + 9.05 triangle tests per ray, maximum todo depth 8."""
     orc = Oracle(path_scene)
     o, d = raygen.incoherent_rays(path_scene.bounds, 200_000, seed=2)
@@ -99,7 +99,7 @@ def test_hits_are_geometrically_consistent(path_scene):
 
 
 def test_path_ray_and_draw_statistics(path_scene):
-    """[survey] Path, cornellBox, depth 15: 3.74 closest-hit + 1.96 any-hit traversals and about 23 random
+    """[measured on the reference] Path, cornellBox, depth 15: 3.74 closest-hit + 1.96 any-hit traversals and about 23 random
     numbers per camera sample (400x400 @ 16 spp on the reference)."""
     cfg = path_scene.config.with_resolution(200, 200, spp=8)
     orc = Oracle(path_scene, cfg)
@@ -112,7 +112,7 @@ def test_path_ray_and_draw_statistics(path_scene):
 
 
 def test_whitted_draw_counts(whitted_scene):
-    """[survey] Whitted on the shipped scene consumes exactly 2 random numbers on a miss and 10 on a hit, and
+    """[measured on the reference] Whitted on the shipped scene consumes exactly 2 random numbers on a miss and 10 on a hit, and
     about 29 % of the camera samples miss all geometry."""
     cfg = whitted_scene.config.with_resolution(111, 83, spp=4)
     orc = Oracle(whitted_scene, cfg)
@@ -184,7 +184,7 @@ def test_full_render_matches_reference_image(path_scene, reference_png):
     oracle and developed to 8 bit, against the reference's cornellBox.png. Because both use the same tile-seeded
     random streams most camera samples are identical; they fork only where libm's last bits differ (the published
     image comes from another C library). Measured: PSNR 46.25 dB, mean |diff| 0.691, max |diff| 28 — the same
-    three numbers the survey obtained from the reference itself compiled on Linux (46.2 dB, 0.69, 28).
+    three numbers obtained from the reference itself compiled on Linux and compared with its image (46.2 dB, 0.69, 28).
     An independent 512-spp render (different streams) sits at 39.7 dB. ~3 minutes on 8 cores."""
     orc = Oracle(path_scene)
     rgb, w, st = orc.render(rng_mode=RT_RNG_REFERENCE_TILE_STREAM)
