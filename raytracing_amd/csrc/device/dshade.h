@@ -267,7 +267,7 @@ RT_DEV float light_pdf_Li(const DevScene &sc, const DevLight &l, f3 refP, f3 wi)
     ray_setup(r, refP, normalize3(wi));
     const float4 q0 = sc.triHot[3 * l.prim + 0], q1 = sc.triHot[3 * l.prim + 1], q2 = sc.triHot[3 * l.prim + 2];
     float t, b0, b1, b2;
-    if (!tri_test(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), RT_INF, t, b0, b1, b2)) return 0;
+    if (!tri_test<false>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), RT_INF, t, b0, b1, b2)) return 0;
     if (q0.w != 0.f) return 0;
     Surf s;
     surface_at(sc, l.prim, b0, b1, b2, s);

@@ -1,0 +1,247 @@
+// Streaming KD-tree tracer: one wave works through a stream of rays and keeps its 64 lanes busy.
+//
+// kd_trace (dtraverse.h) gives one ray to one lane and the wave waits for its slowest lane: on rays that
+// leave surfaces in random directions only about one lane in five does useful work per instruction. Here
+// a lane that finishes its ray takes the next prepared ray from a per-wave pool in LDS, and the wave
+// refills that pool 64 rays at a time with all lanes (ray set-up and the root clip need six divisions, so
+// they are done at full width, never by a few idle lanes). Between refills the wave alternates between
+// rounds of one interior-node step and rounds of one triangle test per lane; a phase is repeated only while
+// most lanes still want it, so coherent rays run as two tight loops and incoherent rays do not wait for
+// the lane with the deepest descent or the biggest leaf. Per ray the node visits, primitive tests and float operations are exactly
+// those of kd_trace, hence of the reference's KdTree::hit pair (src/core/Accelerators/KDTree.cpp:284-490);
+// only the order in which different rays make progress changes.
+//
+// The Job type supplies the rays and consumes the results:
+//   bool fetch(uint32_t j, f3 &o, f3 &d, float &tMax)   ray j of the stream (false: entry j has no ray)
+//   void finish(uint32_t j, const HitRec &h)            called exactly once per fetched ray by the lane that
+//                                                       ended it; h.prim < 0 is a miss, h.t then is tMax
+#pragma once
+#include "dtraverse.h"
+
+#ifndef RT_D_MAJ
+#define RT_D_MAJ 8           // keep descending while at least this many lanes are between leaves
+#endif
+#ifndef RT_T_MAJ
+#define RT_T_MAJ 24          // keep testing while at least this many lanes have leaf primitives left
+#endif
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16     // idle lanes needed before the wave prepares the next 64 rays
+#endif
+#ifndef RT_POP_MIN
+#define RT_POP_MIN 4         // idle lanes needed before prepared rays are handed out
+#endif
+
+
+#define RT_POOL_VEC_PER_RAY 4                                   // uint4 per prepared ray
+#define RT_POOL_BYTES (RT_BLOCK * RT_POOL_VEC_PER_RAY * 16)     // per workgroup: 64 prepared rays per wave
+
+// Prepared ray in the pool: {o, d.x} {d.yz, invDir.xy} {invDir.z, Sx, Sy, Sz} {tMin, tMax, rayTMax, job}
+template <bool CLOSEST, bool STATS, int SL, bool PERM, class Job>
+RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ldsStack, uint4 *ldsPool, uint32_t n, Job &job, TravCounters &cn) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    uint4 *pool = ldsPool + wave * (64 * RT_POOL_VEC_PER_RAY);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t nChunks = (n + 63u) >> 6;
+    // Rays are taken in chunks of 64, chunk c by wave (c mod number of waves): the launch keeps every workgroup
+    // resident, so all waves run from the first ray to the last and equal shares are balanced shares.
+    const uint32_t chunkStride = gridDim.x * (RT_BLOCK / 64);
+    uint32_t chunk = blockIdx.x * (RT_BLOCK / 64) + wave;
+    uint32_t poolCount = 0;
+
+    uint32_t privNode[RT_STACK_TOTAL - SL];
+    float privTMin[RT_STACK_TOTAL - SL], privTMax[RT_STACK_TOTAL - SL];
+
+    // per-lane ray state
+    RayCtx r;
+    r.o = r.d = r.invDir = r.op = mk3(0.f, 0.f, 0.f);
+    r.kz = 2;
+    r.Sx = r.Sy = r.Sz = 0.f;
+    float rayTMax = 0.f, tMin = 0.f, tMax = 0.f;
+    uint32_t node = 0, jobId = 0, leafBase = 0, triBase = 0;
+    int sp = 0, leafI = 0, leafN = 0;
+    HitRec hit = {-1, 0.f, 0.f, 0.f, 0.f};
+    bool active = false;
+
+    // next todo entry; false when the ray is finished (stack empty, or the closest hit so far lies before the entry)
+    auto pop = [&]() -> bool {
+        if (sp == 0) return false;
+        --sp;
+        if (sp < SL) {
+            node = ldsStack[(sp * 3 + 0) * RT_BLOCK + tid];
+            tMin = __uint_as_float(ldsStack[(sp * 3 + 1) * RT_BLOCK + tid]);
+            tMax = __uint_as_float(ldsStack[(sp * 3 + 2) * RT_BLOCK + tid]);
+        } else {
+            const int q = sp - SL;
+            node = privNode[q];
+            tMin = privTMin[q];
+            tMax = privTMax[q];
+        }
+        if (CLOSEST && rayTMax < tMin) return false;
+        return true;
+    };
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (nIdle >= RT_POP_MIN) {
+            if (poolCount == 0 && chunk < nChunks && nIdle >= RT_REFILL_MIN) {
+                // all 64 lanes prepare one ray each, whatever they were doing
+                const uint32_t j = chunk * 64u + lane;
+                chunk += chunkStride;
+                bool valid = false;
+                RayCtx nr;
+                float ntm = 0.f, t0 = 0.f, t1 = 0.f;
+                if (j < n) {
+                    f3 o, d;
+                    if (job.fetch(j, o, d, ntm)) {
+                        if (STATS) ++cn.rays;
+                        ray_setup(nr, o, d);
+                        valid = bounds_clip(sc, nr, ntm, t0, t1);
+                        if (!valid) {
+                            const HitRec miss = {-1, ntm, 0.f, 0.f, 0.f};
+                            job.finish(j, miss);
+                        }
+                    }
+                }
+                const unsigned long long vm = __ballot(valid);
+                if (valid) {
+                    uint4 *e = pool + (uint32_t)__popcll(vm & below) * RT_POOL_VEC_PER_RAY;
+                    e[0] = make_uint4(__float_as_uint(nr.o.x), __float_as_uint(nr.o.y), __float_as_uint(nr.o.z), __float_as_uint(nr.d.x));
+                    e[1] = make_uint4(__float_as_uint(nr.d.y), __float_as_uint(nr.d.z), __float_as_uint(nr.invDir.x), __float_as_uint(nr.invDir.y));
+                    e[2] = make_uint4(__float_as_uint(nr.invDir.z), __float_as_uint(nr.Sx), __float_as_uint(nr.Sy), __float_as_uint(nr.Sz));
+                    e[3] = make_uint4(__float_as_uint(t0), __float_as_uint(t1), __float_as_uint(ntm), j);
+                }
+                poolCount = (uint32_t)__popcll(vm);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (poolCount > 0) {
+                const uint32_t rank = (uint32_t)__popcll(idle & below);
+                if (!active && rank < poolCount) {
+                    const uint4 *e = pool + (poolCount - 1u - rank) * RT_POOL_VEC_PER_RAY;
+                    const uint4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                    r.o = mk3(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e0.z));
+                    r.d = mk3(__uint_as_float(e0.w), __uint_as_float(e1.x), __uint_as_float(e1.y));
+                    r.invDir = mk3(__uint_as_float(e1.z), __uint_as_float(e1.w), __uint_as_float(e2.x));
+                    r.Sx = __uint_as_float(e2.y);
+                    r.Sy = __uint_as_float(e2.z);
+                    r.Sz = __uint_as_float(e2.w);
+                    const f3 a = mk3(fabsf(r.d.x), fabsf(r.d.y), fabsf(r.d.z));
+                    r.kz = (a.x > a.y) ? ((a.x > a.z) ? 0 : 2) : ((a.y > a.z) ? 1 : 2);
+                    r.op = perm3(r.o, r.kz);
+                    triBase = tri_table_base<PERM>(sc, r.kz);
+                    tMin = __uint_as_float(e3.x);
+                    tMax = __uint_as_float(e3.y);
+                    rayTMax = __uint_as_float(e3.z);
+                    jobId = e3.w;
+                    node = 0;
+                    sp = 0;
+                    leafI = leafN = 0;
+                    hit.prim = -1;
+                    hit.t = rayTMax;
+                    hit.b0 = hit.b1 = hit.b2 = 0.f;
+                    active = true;
+                    if (CLOSEST && rayTMax < tMin) {
+                        job.finish(jobId, hit);
+                        active = false;
+                    }
+                }
+                poolCount -= nIdle < poolCount ? nIdle : poolCount;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else if (nIdle == 64u && chunk >= nChunks) {
+                break;
+            }
+        }
+
+        // descend: one node per lane and round; more rounds while most of the wave is still between leaves
+        for (;;) {
+            if (active && leafI >= leafN) {
+                {
+                    const uint2 nd = tb.nodes[node];
+                    if ((nd.y & 3u) != 3u) {
+                        if (STATS) ++cn.interior;
+                        const int axis = (int)(nd.y & 3u);
+                        const float split = __uint_as_float(nd.x);
+                        const float oa = comp3(r.o, axis), da = comp3(r.d, axis), ia = comp3(r.invDir, axis);
+                        const float tPlane = (split - oa) * ia;
+                        const bool belowFirst = (oa < split) || (oa == split && da <= 0);
+                        const uint32_t above = nd.y >> 2;
+                        const uint32_t first = belowFirst ? node + 1 : above;
+                        const uint32_t second = belowFirst ? above : node + 1;
+                        if (tPlane > tMax || tPlane <= 0) {
+                            node = first;
+                        } else if (tPlane < tMin) {
+                            node = second;
+                        } else {
+                            if (sp < SL) {
+                                ldsStack[(sp * 3 + 0) * RT_BLOCK + tid] = second;
+                                ldsStack[(sp * 3 + 1) * RT_BLOCK + tid] = __float_as_uint(tPlane);
+                                ldsStack[(sp * 3 + 2) * RT_BLOCK + tid] = __float_as_uint(tMax);
+                            } else {
+                                const int q = sp - SL;
+                                privNode[q] = second;
+                                privTMin[q] = tPlane;
+                                privTMax[q] = tMax;
+                            }
+                            ++sp;
+                            node = first;
+                            tMax = tPlane;
+                        }
+                    } else {
+                        if (STATS) ++cn.leaf;
+                        const int nP = (int)(nd.y >> 2);
+                        if (nP > 0) {
+                            leafN = nP;
+                            leafI = 0;
+                            leafBase = nd.x;
+                        } else if (!pop()) {   // empty leaf
+                            job.finish(jobId, hit);
+                            active = false;
+                        }
+                    }
+                }
+            }
+            if ((uint32_t)__popcll(__ballot(active && leafI >= leafN)) < RT_D_MAJ) break;
+        }
+        // test: one primitive per lane and round; more rounds while most of the wave is inside leaves
+        for (;;) {
+            if (active && leafI < leafN) {
+                int prim;
+                if (leafN == 1) prim = (int)leafBase;
+                else {
+                    prim = tb.leafIdx[leafBase + (uint32_t)leafI];
+                    if (STATS) ++cn.leafIdx;
+                }
+                if (STATS) ++cn.tri;
+                const float4 q0 = tb.triHot[triBase + 3 * prim + 0];
+                const float4 q1 = tb.triHot[triBase + 3 * prim + 1];
+                const float4 q2 = tb.triHot[triBase + 3 * prim + 2];
+                float t, b0, b1, b2;
+                ++leafI;
+                if (tri_test<PERM>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2)) {
+                    if (!CLOSEST) {
+                        hit.prim = prim;
+                        job.finish(jobId, hit);
+                        active = false;
+                    } else if (q0.w == 0.f) {   // not degenerate
+                        rayTMax = t;
+                        hit.prim = prim;
+                        hit.t = t;
+                        hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+                    }
+                }
+                if (active && leafI == leafN) {
+                    leafI = leafN = 0;
+                    if (!pop()) {
+                        job.finish(jobId, hit);
+                        active = false;
+                    }
+                }
+            }
+            if ((uint32_t)__popcll(__ballot(active && leafI < leafN)) < RT_T_MAJ) break;
+        }
+    }
+}

@@ -40,7 +40,9 @@ struct DevLight {
 //   nodes     uint2  per node   {split | onePrim | indexOffset, axis/leaf flag | child or count << 2}
 //   leafIdx   int    per leaf reference
 //   triHot    float4 x3 per primitive: p0, p1, p2 (w of p0 = 1.0f when the triangle is degenerate for
-//             the closest-hit flavour, TriangleShape.cpp:414-421)
+//             the closest-hit flavour, TriangleShape.cpp:414-421). Scenes small enough for LDS carry three
+//             copies, one per axis permutation of the triangle test (block (kz + 1) % 3 holds the
+//             coordinates permuted for kz; block 0 is the identity), so the test does not permute per ray.
 //   triShade  float4 x5 per primitive: {n0, ss.x} {n1, ss.y} {n2, ss.z} {geometric n, hasNormals}
 //             {materialId, lightId, -, -} — read by shading only
 struct DevScene {
@@ -56,6 +58,7 @@ struct DevScene {
     uint32_t nNodes, nLeafIdx, nPrims, nMats, nLights;
     float lightFuncInt;
     uint32_t ldsSceneBytes;   // nodes + leafIdx + triHot, each padded to 16 B; 0 = does not fit in LDS
+    uint32_t triCopies;       // 3 when triHot holds the permuted copies, else 1
 };
 
 struct RayCtx {
@@ -67,6 +70,7 @@ struct RayCtx {
 
 struct TravCounters {
     uint32_t interior, leaf, leafIdx, tri;
+    uint32_t rays;   // filled by trace_stream only
 };
 
 RT_DEV f3 perm3(f3 v, int kz) {
@@ -107,11 +111,13 @@ RT_DEV bool bounds_clip(const DevScene &sc, const RayCtx &r, float rayTMax, floa
     return true;
 }
 
-// Ray/triangle test. rayTMax is the ray's current m_tMax.
+// Ray/triangle test. rayTMax is the ray's current m_tMax. PERM: the vertices come from the copy of the
+// table that is already permuted for this ray's kz.
+template <bool PERM>
 RT_DEV bool tri_test(const RayCtx &r, f3 p0, f3 p1, f3 p2, float rayTMax, float &tOut, float &b0o, float &b1o, float &b2o) {
-    f3 p0t = perm3(p0, r.kz) - r.op;
-    f3 p1t = perm3(p1, r.kz) - r.op;
-    f3 p2t = perm3(p2, r.kz) - r.op;
+    f3 p0t = (PERM ? p0 : perm3(p0, r.kz)) - r.op;
+    f3 p1t = (PERM ? p1 : perm3(p1, r.kz)) - r.op;
+    f3 p2t = (PERM ? p2 : perm3(p2, r.kz)) - r.op;
     p0t.x += r.Sx * p0t.z; p0t.y += r.Sy * p0t.z;
     p1t.x += r.Sx * p1t.z; p1t.y += r.Sy * p1t.z;
     p2t.x += r.Sx * p2t.z; p2t.y += r.Sy * p2t.z;
@@ -170,7 +176,12 @@ struct SceneTables {
 
 // Stack layout: entry e of lane `tid` lives at stk[(e * 3 + k) * RT_BLOCK + tid] so that lanes at the same depth
 // hit consecutive banks.
-template <bool CLOSEST, bool STATS, int SL>
+// First float4 of the triangle table copy that matches the ray's permutation.
+template <bool PERM> RT_DEV uint32_t tri_table_base(const DevScene &sc, int kz) {
+    return PERM ? (uint32_t)(kz == 2 ? 0 : kz + 1) * sc.nPrims * 3u : 0u;
+}
+
+template <bool CLOSEST, bool STATS, int SL, bool PERM>
 RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsStack, uint32_t tid, const RayCtx &r, float rayTMaxIn,
                      HitRec &hit, TravCounters &cn) {
     float tMin, tMax;
@@ -185,6 +196,7 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
     int sp = 0;
     uint32_t node = 0;
     bool found = false;
+    const float4 *tris = tb.triHot + tri_table_base<PERM>(sc, r.kz);
     for (;;) {
         if (CLOSEST && rayTMax < tMin) break;
         uint2 nd = tb.nodes[node];
@@ -230,11 +242,11 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
                 if (STATS) ++cn.leafIdx;
             }
             if (STATS) ++cn.tri;
-            const float4 q0 = tb.triHot[3 * prim + 0];
-            const float4 q1 = tb.triHot[3 * prim + 1];
-            const float4 q2 = tb.triHot[3 * prim + 2];
+            const float4 q0 = tris[3 * prim + 0];
+            const float4 q1 = tris[3 * prim + 1];
+            const float4 q2 = tris[3 * prim + 2];
             float t, b0, b1, b2;
-            if (tri_test(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2)) {
+            if (tri_test<PERM>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2)) {
                 if (!CLOSEST) { hit.prim = prim; return true; }
                 if (q0.w == 0.f) {   // not degenerate
                     rayTMax = t;
@@ -265,7 +277,7 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
 RT_DEV void stage_scene_lds(const DevScene &sc, uint4 *smem, SceneTables &tb) {
     const uint32_t nodeVec = (sc.nNodes * 8 + 15) / 16;
     const uint32_t idxVec = (sc.nLeafIdx * 4 + 15) / 16;
-    const uint32_t triVec = sc.nPrims * 3;
+    const uint32_t triVec = sc.nPrims * 3 * sc.triCopies;
     const uint4 *gn = reinterpret_cast<const uint4 *>(sc.nodes);
     const uint4 *gi = reinterpret_cast<const uint4 *>(sc.leafIdx);
     const uint4 *gt = reinterpret_cast<const uint4 *>(sc.triHot);

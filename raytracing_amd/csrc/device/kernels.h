@@ -2,6 +2,7 @@
 // (raygen -> [extend -> shade -> shadow -> probe] per bounce -> film) and the Whitted integrator.
 #pragma once
 #include "dshade.h"
+#include "dstream.h"
 
 // ---------------------------------------------------------------------------------------------------
 // device-side counters (one array per context)
@@ -44,10 +45,13 @@ RT_DEV void flush_counters(unsigned long long *stats, const TravCounters &cn, ui
 // Dynamic LDS layout of every tracing kernel: [todo stack: LDS_N*3*RT_BLOCK dwords][scene tables]
 template <bool LDS_SCENE> RT_HD constexpr uint32_t stack_lds_bytes() { return StackCfg<LDS_SCENE>::LDS_N * 3 * RT_BLOCK * 4; }
 
+// Dynamic LDS layout of the streaming kernels: [todo stack][prepared-ray pool: RT_POOL_BYTES][scene tables]
+template <bool LDS_SCENE> RT_HD constexpr uint32_t stream_lds_bytes() { return stack_lds_bytes<LDS_SCENE>() + RT_POOL_BYTES; }
+
 template <bool LDS_SCENE>
-RT_DEV void tables_setup(const DevScene &sc, uint4 *smem, SceneTables &tb) {
+RT_DEV void tables_setup(const DevScene &sc, uint4 *smem, SceneTables &tb, uint32_t sceneOffsetBytes = stack_lds_bytes<LDS_SCENE>()) {
     if (LDS_SCENE) {
-        stage_scene_lds(sc, smem + stack_lds_bytes<LDS_SCENE>() / 16, tb);
+        stage_scene_lds(sc, smem + sceneOffsetBytes / 16, tb);
     } else {
         tb.nodes = sc.nodes;
         tb.leafIdx = sc.leafIdx;
@@ -58,6 +62,9 @@ RT_DEV void tables_setup(const DevScene &sc, uint4 *smem, SceneTables &tb) {
 // ---------------------------------------------------------------------------------------------------
 // batch tracing (rt_trace_closest / rt_trace_any)
 // ---------------------------------------------------------------------------------------------------
+// Two schedules (rt_set_option RT_OPTION_TRACE_SCHEDULE). Lockstep: one ray per lane, the wave waits for its
+// slowest lane; best for coherent batches (camera rays) and small batches. Streaming (dstream.h): lanes take
+// new rays as they finish; best for large batches of incoherent rays.
 template <bool LDS_SCENE, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                             const float *__restrict__ tmax, int *__restrict__ prim, float *__restrict__ tOut,
@@ -66,13 +73,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
-    TravCounters cn = {0, 0, 0, 0};
+    TravCounters cn = {0, 0, 0, 0, 0};
     uint32_t myRays = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RT_BLOCK) {
         RayCtx r;
         ray_setup(r, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
         HitRec h;
-        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
+        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
         if (prim) prim[i] = h.prim;
         if (tOut) tOut[i] = h.t;
         if (bary) { bary[3 * i] = h.b0; bary[3 * i + 1] = h.b1; bary[3 * i + 2] = h.b2; }
@@ -89,17 +96,79 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DevScene sc, uint64_t n,
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
-    TravCounters cn = {0, 0, 0, 0};
+    TravCounters cn = {0, 0, 0, 0, 0};
     uint32_t myRays = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RT_BLOCK) {
         RayCtx r;
         ray_setup(r, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
         HitRec h;
-        const bool hit = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
+        const bool hit = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
         occluded[i] = hit ? 1 : 0;
         ++myRays;
     }
     if (STATS) flush_counters(stats, cn, myRays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
+}
+
+struct TraceClosestJob {
+    const float *o, *d, *tmax;
+    int *prim;
+    float *tOut, *bary;
+    RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
+        const size_t i = j;
+        ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        tm = tmax ? tmax[i] : RT_INF;
+        return true;
+    }
+    RT_DEV void finish(uint32_t j, const HitRec &h) const {
+        const size_t i = j;
+        if (prim) prim[i] = h.prim;
+        if (tOut) tOut[i] = h.t;
+        if (bary) { bary[3 * i] = h.b0; bary[3 * i + 1] = h.b1; bary[3 * i + 2] = h.b2; }
+    }
+};
+
+struct TraceAnyJob {
+    const float *o, *d, *tmax;
+    uint8_t *occluded;
+    RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
+        const size_t i = j;
+        ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        tm = tmax ? tmax[i] : RT_INF;
+        return true;
+    }
+    RT_DEV void finish(uint32_t j, const HitRec &h) const { occluded[j] = h.prim >= 0 ? 1 : 0; }
+};
+
+// Streaming flavours. n < 2^32 (the host splits larger batches); the grid must be resident as a whole.
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_stream(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
+                                                                   const float *__restrict__ tmax, int *__restrict__ prim, float *__restrict__ tOut,
+                                                                   float *__restrict__ bary, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
+    TravCounters cn = {0, 0, 0, 0, 0};
+    TraceClosestJob job = {o, d, tmax, prim, tOut, bary};
+    trace_stream<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16,
+                                                                      (uint32_t)n, job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+}
+
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_any_stream(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
+                                                               const float *__restrict__ tmax, uint8_t *__restrict__ occluded, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
+    TravCounters cn = {0, 0, 0, 0, 0};
+    TraceAnyJob job = {o, d, tmax, occluded};
+    trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16,
+                                                                       (uint32_t)n, job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }
 
@@ -124,10 +193,11 @@ struct PathBuffers {
 };
 
 // Queue counters: one 128-byte line per counter so that appends to different queues do not serialise on one
-// L2 line. Counter q of bounce b lives at counts[(b * 3 + q) * RT_CNT_STRIDE]; q: 0 = rays entering bounce b,
-// 1 = shadow entries of bounce b, 2 = probe entries of bounce b.
+// L2 line. Counter q of bounce b lives at counts[(b * RT_CNT_PER_BOUNCE + q) * RT_CNT_STRIDE]; q: 0 = rays entering
+// bounce b, 1 = shadow entries of bounce b, 2 = probe entries of bounce b.
 #define RT_CNT_STRIDE 32
-RT_HD uint32_t cnt_index(int bounce, int q) { return (uint32_t)(bounce * 3 + q) * RT_CNT_STRIDE; }
+#define RT_CNT_PER_BOUNCE 3
+RT_HD uint32_t cnt_index(int bounce, int q) { return (uint32_t)(bounce * RT_CNT_PER_BOUNCE + q) * RT_CNT_STRIDE; }
 
 struct PassInfo {
     uint32_t nPix;         // pixels in the sample bounds
@@ -210,14 +280,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
-    TravCounters cn = {0, 0, 0, 0};
+    TravCounters cn = {0, 0, 0, 0, 0};
     uint32_t myRays = 0;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const float4 a = rayA[i], b = rayB[i];
         RayCtx r;
         ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
         HitRec h;
-        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
         hit[i] = make_float4(__int_as_float(h.prim), h.b0, h.b1, h.b2);
         ++myRays;
     }
@@ -405,7 +475,7 @@ RT_DEV void shadow_entries(const DevScene &sc, const SceneTables &tb, uint32_t *
         RayCtx r;
         ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
         HitRec h;
-        const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
+        const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
         if (!occluded) {
             const uint32_t pathId = __float_as_uint(b.z);
             float4 L4 = pb.L[pathId];
@@ -437,7 +507,7 @@ RT_DEV void probe_entries(const DevScene &sc, const SceneTables &tb, uint32_t *s
             RayCtx r;
             ray_setup(r, p, mk3(e1.x, e1.y, e1.z));
             HitRec h;
-            const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
+            const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
             if (!occluded) Ld = Ld + mk3(e2.x, e2.y, e2.z);
             ++myRays;
             ++nShadow;
@@ -447,7 +517,7 @@ RT_DEV void probe_entries(const DevScene &sc, const SceneTables &tb, uint32_t *s
             RayCtx r;
             ray_setup(r, p, normalize3(wi));
             HitRec h;
-            const bool found = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+            const bool found = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
             ++myRays;
             f3 Li = mk3(0.f, 0.f, 0.f);
             if (found) {
@@ -594,7 +664,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
             ray_setup(r, ro, rdir);
             HitRec h;
             ++nClosest;
-            const bool hit = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+            const bool hit = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
             Lret = mk3(0.f, 0.f, 0.f);
             state = RETURN;
             if (hit) {
@@ -618,7 +688,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
                         ray_setup(sr, sf.p, normalize3(pShape - sf.p));
                         HitRec sh;
                         ++nAny;
-                        if (!kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N>(sc, tb, stk, threadIdx.x, sr, 1 - RT_SHADOW_EPS, sh, cn))
+                        if (!kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, sr, 1 - RT_SHADOW_EPS, sh, cn))
                             L = L + f * Li * absdot3(wi, sf.n) / pdf;
                     }
                 }

@@ -4,7 +4,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -27,6 +29,7 @@ struct rt_context {
     std::string err;
     int numCUs = 256;
     int gridBlocks = 2048;
+    std::map<const void *, int> residentGrid;   // streaming kernels: blocks that are resident at once, per kernel
 
     // scene
     bool haveScene = false;
@@ -43,6 +46,7 @@ struct rt_context {
 
     // stats
     unsigned long long *dStats = nullptr;
+    int traceSchedule = RT_SCHEDULE_LOCKSTEP;
     std::vector<EventPair> extendEvents;
     size_t extendEventsUsed = 0;
     double renderMs = 0;
@@ -142,6 +146,7 @@ int upload(rt_context *c, void **dst, const std::vector<T> &v, size_t padBytes =
 }
 
 size_t trace_lds_bytes(const rt_context *c) { return c->ldsScene ? stack_lds_bytes<true>() + c->sc.ldsSceneBytes : stack_lds_bytes<false>(); }
+size_t stream_lds_bytes_of(const rt_context *c) { return c->ldsScene ? stream_lds_bytes<true>() + c->sc.ldsSceneBytes : stream_lds_bytes<false>(); }
 
 int ensure_spill(rt_context *c) {
     const size_t n = (size_t)c->cam.width * c->cam.height;
@@ -180,7 +185,7 @@ int ensure_path_buffers(rt_context *c, size_t nPaths, int maxDepth) {
         if ((rc = alloc((void **)&pb.shB, nPaths * 16))) return rc;
         if ((rc = alloc((void **)&pb.shC, nPaths * 16))) return rc;
         if ((rc = alloc((void **)&pb.probe, nPaths * 16 * 6))) return rc;
-        if ((rc = alloc((void **)&pb.counts, (size_t)(maxDepth + 2) * 3 * RT_CNT_STRIDE * sizeof(uint32_t)))) return rc;
+        if ((rc = alloc((void **)&pb.counts, (size_t)(maxDepth + 2) * RT_CNT_PER_BOUNCE * RT_CNT_STRIDE * sizeof(uint32_t)))) return rc;
     }
     c->pbCapacity = nPaths;
     c->pbDepth = maxDepth;
@@ -198,29 +203,72 @@ EventPair *next_event_pair(rt_context *c) {
     return &c->extendEvents[c->extendEventsUsed++];
 }
 
-template <typename... Args>
-void launch_trace_kernel(rt_context *c, bool stats, void (*kLdsStats)(Args...), void (*kLds)(Args...), void (*kGlobStats)(Args...),
-                         void (*kGlob)(Args...), int grid, Args... args) {
+// Grid of a streaming kernel: the workgroups the device keeps resident at once, so that every wave runs from the
+// first ray to the last and the static chunk -> wave assignment is balanced.
+template <typename K>
+int resident_grid(rt_context *c, K kernel, size_t ldsBytes) {
+    const void *key = reinterpret_cast<const void *>(kernel);
+    auto it = c->residentGrid.find(key);
+    if (it != c->residentGrid.end()) return it->second;
+    int perCU = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, RT_BLOCK, ldsBytes) != hipSuccess || perCU <= 0) perCU = 4;
+    const int grid = c->numCUs * std::min(perCU, 8);
+    c->residentGrid[key] = grid;
+    return grid;
+}
+
+template <typename... KArgs, typename... Args>
+void launch_lockstep(rt_context *c, bool stats, void (*kLdsStats)(KArgs...), void (*kLds)(KArgs...), void (*kGlobStats)(KArgs...),
+                     void (*kGlob)(KArgs...), uint64_t n, Args... args) {
     auto k = c->ldsScene ? (stats ? kLdsStats : kLds) : (stats ? kGlobStats : kGlob);
+    const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)c->gridBlocks);
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), trace_lds_bytes(c), c->stream, args...);
 }
 
+template <typename... KArgs, typename... Args>
+void launch_stream(rt_context *c, bool stats, void (*kLdsStats)(KArgs...), void (*kLds)(KArgs...), void (*kGlobStats)(KArgs...),
+                   void (*kGlob)(KArgs...), uint64_t n, Args... args) {
+    auto k = c->ldsScene ? (stats ? kLdsStats : kLds) : (stats ? kGlobStats : kGlob);
+    const size_t lds = stream_lds_bytes_of(c);
+    const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)resident_grid(c, k, lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, args...);
+}
+
+// The streaming kernels index rays with 32 bits: larger batches are cut into several launches.
+constexpr uint64_t kMaxRaysPerLaunch = 1ull << 31;
+
 int trace_closest_dev(rt_context *c, uint64_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary,
                       bool stats) {
-    if (n == 0) return RT_OK;
-    const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)c->gridBlocks);
-    launch_trace_kernel(c, stats, k_trace_closest<true, true>, k_trace_closest<true, false>, k_trace_closest<false, true>,
-                        k_trace_closest<false, false>, grid, c->sc, n, o, d, tmax, prim, t, bary, c->dStats);
-    HIPCHK(c, hipGetLastError());
+    for (uint64_t base = 0; base < n; base += kMaxRaysPerLaunch) {
+        const uint64_t m = std::min<uint64_t>(kMaxRaysPerLaunch, n - base);
+        const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
+        int32_t *prim_ = prim ? prim + base : nullptr;
+        float *t_ = t ? t + base : nullptr, *bary_ = bary ? bary + 3 * base : nullptr;
+        if (c->traceSchedule == RT_SCHEDULE_STREAM) {
+            launch_stream(c, stats, k_trace_closest_stream<true, true>, k_trace_closest_stream<true, false>, k_trace_closest_stream<false, true>,
+                          k_trace_closest_stream<false, false>, m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
+        } else {
+            launch_lockstep(c, stats, k_trace_closest<true, true>, k_trace_closest<true, false>, k_trace_closest<false, true>,
+                            k_trace_closest<false, false>, m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
     return RT_OK;
 }
 
 int trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, const float *tmax, uint8_t *occ, bool stats) {
-    if (n == 0) return RT_OK;
-    const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)c->gridBlocks);
-    launch_trace_kernel(c, stats, k_trace_any<true, true>, k_trace_any<true, false>, k_trace_any<false, true>, k_trace_any<false, false>, grid,
-                        c->sc, n, o, d, tmax, occ, c->dStats);
-    HIPCHK(c, hipGetLastError());
+    for (uint64_t base = 0; base < n; base += kMaxRaysPerLaunch) {
+        const uint64_t m = std::min<uint64_t>(kMaxRaysPerLaunch, n - base);
+        const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
+        if (c->traceSchedule == RT_SCHEDULE_STREAM) {
+            launch_stream(c, stats, k_trace_any_stream<true, true>, k_trace_any_stream<true, false>, k_trace_any_stream<false, true>,
+                          k_trace_any_stream<false, false>, m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
+        } else {
+            launch_lockstep(c, stats, k_trace_any<true, true>, k_trace_any<true, false>, k_trace_any<false, true>, k_trace_any<false, false>, m,
+                            c->sc, m, o_, d_, tm_, occ + base, c->dStats);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
     return RT_OK;
 }
 
@@ -268,7 +316,8 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     int lastPipe = -1;
     int passIndex = 0;
     for (int s0 = p->spp_begin; s0 < p->spp_end; s0 += sppPass, ++passIndex) {
-        const int k = passIndex % rt_context::kPipes;
+        static const int pipesInUse = std::getenv("RT_AMD_SINGLE_PIPE") ? 1 : rt_context::kPipes;   // profiling aid: kernels run one at a time
+        const int k = passIndex % pipesInUse;
         PathBuffers &pb = c->pb[k];
         hipStream_t st = c->pipeStream[k];
         PassInfo ps;
@@ -280,7 +329,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
         ps.seed = p->seed;
         ps.maxDepth = p->max_depth;
         ps.rrThreshold = p->rr_threshold;
-        HIPCHK(c, hipMemsetAsync(pb.counts, 0, (size_t)(p->max_depth + 2) * 3 * RT_CNT_STRIDE * sizeof(uint32_t), st));
+        HIPCHK(c, hipMemsetAsync(pb.counts, 0, (size_t)(p->max_depth + 2) * RT_CNT_PER_BOUNCE * RT_CNT_STRIDE * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cam, ps, pb, c->dStats);
         for (int b = 0; b <= p->max_depth; ++b) {
             const int cur = b & 1;
@@ -450,7 +499,11 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     free_scene(c);
 
     const uint32_t np = d->n_prims;
-    std::vector<float4> hot((size_t)np * 3), shade((size_t)np * 5);
+    // scenes whose traversal tables fit in LDS carry the triangle positions in all three axis permutations
+    const size_t ldsBytes = (((size_t)d->n_nodes * 8 + 15) / 16 + ((size_t)d->n_leaf_idx * 4 + 15) / 16 + (size_t)np * 3 * 3) * 16;
+    c->ldsScene = ldsBytes <= 40 * 1024;
+    const uint32_t triCopies = c->ldsScene ? 3u : 1u;
+    std::vector<float4> hot((size_t)np * 3 * triCopies), shade((size_t)np * 5);
     for (uint32_t i = 0; i < np; ++i) {
         const float *p = &d->tri_p[9 * (size_t)i];
         f3 ss, ng;
@@ -459,6 +512,11 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
         hot[3 * (size_t)i + 0] = make_float4(p[0], p[1], p[2], degenerate ? 1.f : 0.f);
         hot[3 * (size_t)i + 1] = make_float4(p[3], p[4], p[5], 0.f);
         hot[3 * (size_t)i + 2] = make_float4(p[6], p[7], p[8], 0.f);
+        for (uint32_t b = 1; b < triCopies; ++b) {   // block b serves kz = b - 1: (y,z,x) for kz 0, (z,x,y) for kz 1
+            const int kx = (int)b % 3, ky = (kx + 1) % 3, kzz = (int)b - 1;
+            for (int v = 0; v < 3; ++v)
+                hot[((size_t)b * np + i) * 3 + v] = make_float4(p[3 * v + kx], p[3 * v + ky], p[3 * v + kzz], v == 0 && degenerate ? 1.f : 0.f);
+        }
         const bool hasN = d->tri_n && (!d->tri_has_n || d->tri_has_n[i]);
         const float *nn = hasN ? &d->tri_n[9 * (size_t)i] : nullptr;
         shade[5 * (size_t)i + 0] = make_float4(nn ? nn[0] : 0.f, nn ? nn[1] : 0.f, nn ? nn[2] : 0.f, ss.x);
@@ -527,8 +585,8 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     sc.nMats = d->n_materials;
     sc.nLights = d->n_lights;
     sc.lightFuncInt = funcInt;
-    const size_t ldsBytes = (((size_t)d->n_nodes * 8 + 15) / 16 + ((size_t)d->n_leaf_idx * 4 + 15) / 16 + (size_t)np * 3) * 16;
-    c->ldsScene = ldsBytes <= 40 * 1024;
+    sc.triCopies = triCopies;
+    c->residentGrid.clear();
     sc.ldsSceneBytes = c->ldsScene ? (uint32_t)ldsBytes : 0;
     c->haveScene = true;
     return RT_OK;
@@ -660,6 +718,16 @@ int rt_synchronize(rt_context *c) {
 }
 
 void *rt_stream(rt_context *c) { return c ? (void *)c->stream : nullptr; }
+
+int rt_set_option(rt_context *c, int option, int value) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (option == RT_OPTION_TRACE_SCHEDULE) {
+        if (value != RT_SCHEDULE_LOCKSTEP && value != RT_SCHEDULE_STREAM) return fail(c, RT_ERR_INVALID_ARG, "unknown trace schedule");
+        c->traceSchedule = value;
+        return RT_OK;
+    }
+    return fail(c, RT_ERR_INVALID_ARG, "unknown option");
+}
 
 int rt_get_stats(rt_context *c, rt_stats *out) {
     if (!c || !out) return RT_ERR_INVALID_ARG;

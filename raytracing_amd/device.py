@@ -15,7 +15,7 @@ _dev = None
 EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_version", "rt_upload_scene", "rt_set_camera", "rt_trace_closest",
     "rt_trace_any", "rt_trace_closest_dev", "rt_trace_any_dev", "rt_render", "rt_render_dev", "rt_synchronize", "rt_stream",
-    "rt_get_stats", "rt_reset_stats",
+    "rt_get_stats", "rt_reset_stats", "rt_set_option",
 ]
 
 
@@ -23,7 +23,7 @@ def device_lib():
     """Loads libraytracing_amd.so. Raises if it has not been built (run `make device`)."""
     global _dev
     if _dev is None:
-        path = os.path.join(_LIB_DIR, "libraytracing_amd.so")
+        path = os.environ.get("RT_AMD_DEVICE_LIB") or os.path.join(_LIB_DIR, "libraytracing_amd.so")   # override: experiments
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with `make device` (or __graft_entry__.build()); "
                                "there is no CPU fallback for the device path")
@@ -48,6 +48,7 @@ def device_lib():
         lib.rt_stream.restype = vp
         lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
         lib.rt_reset_stats.argtypes = [vp]
+        lib.rt_set_option.argtypes = [vp, i32, i32]
         _dev = lib
     return _dev
 
@@ -168,6 +169,10 @@ class Context:
                          kw.get("spp_begin", 0), kw.get("spp_end"), kw.get("spp_per_pass", 0), kw.get("collect_stats", False),
                          kw.get("rr_threshold", 1.0))
         self._check(self._lib.rt_render_dev(self._h, C.byref(p), rgb_ptr, weight_ptr))
+
+    def set_trace_schedule(self, stream):
+        """Batch tracers: False = one ray per lane (default), True = lanes take new rays as they finish."""
+        self._check(self._lib.rt_set_option(self._h, 1, 1 if stream else 0))
 
     def synchronize(self):
         self._check(self._lib.rt_synchronize(self._h))

@@ -10,6 +10,14 @@ from oracle_lib import Oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["lockstep", "stream"])
+def trace_schedule(request, gpu_ctx):
+    """Every test of this module runs under both ray-to-lane schedules of the batch tracers."""
+    gpu_ctx.set_trace_schedule(request.param == "stream")
+    yield request.param
+    gpu_ctx.set_trace_schedule(False)
+
+
 def _compare_closest(ctx, orc, o, d, tmax=None, label=""):
     gp, gt, gb = ctx.trace_closest(o, d, tmax)
     cp, ct, cb = orc.trace_closest(o, d, tmax)

@@ -26,5 +26,5 @@ i0, i1 = idx[-3], idx[-2]
 line = []
 for n,s,e in rows[i0:i1]:
     line.append('%s:%.0f' % (n.replace('void ','')[:8], (e-s)/1e3))
-print('one pass (us): ' + ' '.join(line[:26]) + ' ... pass total %.2f ms' % ((rows[i1][1]-rows[i0][1])/1e6))
+print('one pass (us): ' + ' '.join(line[:40]) + ' ... pass total %.2f ms' % ((rows[i1][1]-rows[i0][1])/1e6))
 PY

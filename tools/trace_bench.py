@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Throughput of rt_trace_closest_dev / rt_trace_any_dev on three ray distributions over the cornellBox
+fixture: camera rays (coherent), rays leaving surfaces in random directions (the bounce rays of the path
+tracer) and rays with uniform origins and directions. usage: tools/trace_bench.py [n_rays] [repeats]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from raytracing_amd.device import Context  # noqa: E402
+from raytracing_amd.scene import FlatScene, camera_ray  # noqa: E402
+import raygen  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 23
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    scene = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornellBox_path.npz"))
+    cfg = scene.config.with_resolution(1920, 1080)
+    ctx = Context(0)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cfg)
+    dev = torch.device("cuda", 0)
+    prim = torch.empty(n, dtype=torch.int32, device=dev)
+    t = torch.empty(n, dtype=torch.float32, device=dev)
+    bary = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    occ = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def timed(fn):
+        fn()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def run(name, o, d):
+        o = o.contiguous()
+        d = d.contiguous()
+        torch.cuda.synchronize()
+        for stream in (False, True):
+            ctx.set_trace_schedule(stream)
+            run1(name + (" stream" if stream else " lockstep"), o, d)
+
+    def run1(name, o, d):
+        dt = timed(lambda: ctx.trace_closest_dev(n, o.data_ptr(), d.data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr()))
+        da = timed(lambda: ctx.trace_any_dev(n, o.data_ptr(), d.data_ptr(), 0, occ.data_ptr()))
+        ctx.synchronize()
+        print(f"{name:>16}: closest {n / dt / 1e9:7.2f} Grays/s ({dt * 1e3:7.3f} ms)   any {n / da / 1e9:7.2f} Grays/s   "
+              f"hit {float((prim >= 0).float().mean()):.3f} checksum {int(prim.long().sum())} {float(t[prim >= 0].double().sum()):.6e}")
+
+    # camera rays in pixel order (pinhole at the camera position; directions through a regular grid)
+    eye, dir00 = [np.asarray(v, np.float32) for v in camera_ray(cfg, 0.5, 0.5)]
+    _, dir10 = [np.asarray(v, np.float32) for v in camera_ray(cfg, cfg.width - 0.5, 0.5)]
+    _, dir01 = [np.asarray(v, np.float32) for v in camera_ray(cfg, 0.5, cfg.height - 0.5)]
+    side = int(np.sqrt(n))
+    u = torch.linspace(0, 1, side, device=dev)
+    gy, gx = torch.meshgrid(u, u, indexing="ij")
+    d00, d10, d01 = [torch.tensor(v, device=dev) for v in (dir00, dir10, dir01)]
+    dcam = d00 + gx.reshape(-1, 1) * (d10 - d00) + gy.reshape(-1, 1) * (d01 - d00)
+    dcam = torch.nn.functional.normalize(dcam, dim=1)
+    if dcam.shape[0] < n:
+        dcam = torch.cat([dcam, dcam[: n - dcam.shape[0]]])
+    ocam = torch.tensor(eye, device=dev).expand(n, 3)
+    run("camera", ocam, dcam)
+
+    # bounce rays: start at the camera rays' hit points, uniform random directions
+    p = ocam + t.unsqueeze(1) * dcam
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    drand = torch.nn.functional.normalize(torch.randn((n, 3), device=dev, generator=g), dim=1)
+    keep = prim >= 0
+    p = torch.where(keep.unsqueeze(1), p, torch.tensor(eye, device=dev).expand(n, 3))
+    run("bounce", p, drand)
+
+    o, d = raygen.incoherent_rays(scene.bounds, n, 3)
+    run("uniform", torch.tensor(o, device=dev), torch.tensor(d, device=dev))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
