@@ -29,6 +29,11 @@ SPP_PER_STEP = 8
 MAX_DEPTH = 15
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 FP32_VALU_PEAK_TFLOPS = 157.3
+# HBM-side bytes per ray of k_extend from the hardware counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# passes over this workload, profiles/r01_pmc_bench_steps4.md): 2 x 17.2 B read (gfx950 counts the 16-B-per-lane
+# coalesced reads at half their bytes) + 17.5 B written. Counters cannot be read inside a timed run, so the figure
+# measured under the profiler is scaled by this run's rays per launch.
+EXTEND_HBM_BYTES_PER_RAY_PMC = 52.0
 
 
 def bytes_per_ray(ni, nl, nidx, ntri, closest=True):
@@ -187,14 +192,16 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": EXTEND_HBM_BYTES_PER_RAY_PMC * ext_rays / ext_launches,
+                "traffic_unit": "bytes per launch (HBM side, PMC)",
                 "bytes_per_ray": bpr,
                 "rays_per_launch": ext_rays / ext_launches,
                 "avg_launch_ms": ext_ms / ext_launches,
                 "launches": int(ext_launches),
                 "per_ray": {"interior": ni, "leaf": nl, "leaf_idx": nidx, "tri_tests": ntri},
-                "note": "algorithmic bytes (served from LDS for this 4 KB scene, so they are not HBM traffic); "
-                        "the kernel is VALU/latency-bound here, see valu",
+                "note": "algorithmic bytes (nodes, leaf indices and triangles are served from LDS for this 8 KB scene, so only the "
+                        "ray and hit records are HBM traffic); the kernel is bound by SIMD divergence (12.6 of 64 lanes active per "
+                        "VALU instruction, PMC), see valu",
                 "valu": {"achieved": valu, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu / FP32_VALU_PEAK_TFLOPS,
                          "flops_per_ray": fpr},
                 "extend_share_of_step": ext_ms * 1e-3 / t,
