@@ -158,14 +158,16 @@ int rt_trace_closest(rt_context *ctx, uint64_t n, const float *o_xyz, const floa
 /* Any hit: KdTree::hit(ray) (Accelerators/KDTree.cpp:284-383). occluded[i] = 1 when something is hit. */
 int rt_trace_any(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d_xyz,
                  const float *tmax, uint8_t *occluded);
-/* How the batch tracers map rays to lanes. No counterpart in the reference (its CPU loop has no such choice);
- * results are identical under both, only the speed differs.
- *   RT_SCHEDULE_LOCKSTEP (default): one ray per lane, a wave ends with its slowest ray. Fastest for coherent
- *                                   batches (camera rays in pixel order) and for batches below ~1 M rays.
- *   RT_SCHEDULE_STREAM:             lanes pick up the next ray as soon as theirs ends. Fastest for large batches of
- *                                   incoherent rays (about 1.3x-1.4x on random rays in the cornellBox scene). */
+/* How traversal maps rays to lanes. No counterpart in the reference (its CPU loop has no such choice); results
+ * are identical under all settings, only the speed differs.
+ *   RT_SCHEDULE_AUTO (default): LOCKSTEP for scenes whose traversal tables fit in LDS, STREAM otherwise.
+ *   RT_SCHEDULE_LOCKSTEP:       one ray per lane, a wave ends with its slowest ray. Fastest for coherent batches and
+ *                               small scenes (cornellBox camera rays: 37 vs 23 G rays/s).
+ *   RT_SCHEDULE_STREAM:         lanes pick up the next ray as soon as theirs ends. Fastest for incoherent rays and for
+ *                               scenes in HBM (1 M-triangle soup, incoherent rays: 0.63 vs 0.36 G rays/s).
+ * Applies to rt_trace_* and, for scenes in HBM, to the extend and shadow stages of rt_render. */
 enum { RT_OPTION_TRACE_SCHEDULE = 1 };
-enum { RT_SCHEDULE_LOCKSTEP = 0, RT_SCHEDULE_STREAM = 1 };
+enum { RT_SCHEDULE_AUTO = 0, RT_SCHEDULE_LOCKSTEP = 1, RT_SCHEDULE_STREAM = 2 };
 int rt_set_option(rt_context *ctx, int option, int value);
 
 /* Same, all pointers in device memory, asynchronous on the context's stream (call rt_synchronize). */

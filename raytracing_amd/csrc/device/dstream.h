@@ -50,7 +50,7 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
     uint32_t poolCount = 0;
 
     uint32_t privNode[RT_STACK_TOTAL - SL];
-    float privTMin[RT_STACK_TOTAL - SL], privTMax[RT_STACK_TOTAL - SL];
+    float privTMax[RT_STACK_TOTAL - SL];
 
     // per-lane ray state
     RayCtx r;
@@ -67,14 +67,13 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
     auto pop = [&]() -> bool {
         if (sp == 0) return false;
         --sp;
+        tMin = tMax;   // the segment after the one just finished starts where that one ended
         if (sp < SL) {
-            node = ldsStack[(sp * 3 + 0) * RT_BLOCK + tid];
-            tMin = __uint_as_float(ldsStack[(sp * 3 + 1) * RT_BLOCK + tid]);
-            tMax = __uint_as_float(ldsStack[(sp * 3 + 2) * RT_BLOCK + tid]);
+            node = ldsStack[(sp * 2 + 0) * RT_BLOCK + tid];
+            tMax = __uint_as_float(ldsStack[(sp * 2 + 1) * RT_BLOCK + tid]);
         } else {
             const int q = sp - SL;
             node = privNode[q];
-            tMin = privTMin[q];
             tMax = privTMax[q];
         }
         if (CLOSEST && rayTMax < tMin) return false;
@@ -177,13 +176,11 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                             node = second;
                         } else {
                             if (sp < SL) {
-                                ldsStack[(sp * 3 + 0) * RT_BLOCK + tid] = second;
-                                ldsStack[(sp * 3 + 1) * RT_BLOCK + tid] = __float_as_uint(tPlane);
-                                ldsStack[(sp * 3 + 2) * RT_BLOCK + tid] = __float_as_uint(tMax);
+                                ldsStack[(sp * 2 + 0) * RT_BLOCK + tid] = second;
+                                ldsStack[(sp * 2 + 1) * RT_BLOCK + tid] = __float_as_uint(tMax);
                             } else {
                                 const int q = sp - SL;
                                 privNode[q] = second;
-                                privTMin[q] = tPlane;
                                 privTMax[q] = tMax;
                             }
                             ++sp;

@@ -19,7 +19,7 @@
 #define RT_STACK_LDS_SMALL 4
 #endif
 #ifndef RT_STACK_LDS_LARGE
-#define RT_STACK_LDS_LARGE 8
+#define RT_STACK_LDS_LARGE 12
 #endif
 template <bool LDS_SCENE> struct StackCfg { static constexpr int LDS_N = LDS_SCENE ? RT_STACK_LDS_SMALL : RT_STACK_LDS_LARGE; };
 
@@ -174,8 +174,11 @@ struct SceneTables {
     const float4 *triHot;
 };
 
-// Stack layout: entry e of lane `tid` lives at stk[(e * 3 + k) * RT_BLOCK + tid] so that lanes at the same depth
-// hit consecutive banks.
+// Todo stack. The reference's entries are (node, tMin, tMax) (Accelerators/KDTree.h:48-52). tMin is not stored
+// here: an entry's tMin is the split-plane distance that became the current tMax when the entry was pushed, and
+// every push/pop pair below it restores tMax, so at the moment the entry is popped the current tMax holds exactly
+// that value. Entry e of lane `tid` lives at stk[(e * 2 + k) * RT_BLOCK + tid] (k = 0 node, 1 tMax) so that lanes at
+// the same depth hit consecutive banks.
 // First float4 of the triangle table copy that matches the ray's permutation.
 template <bool PERM> RT_DEV uint32_t tri_table_base(const DevScene &sc, int kz) {
     return PERM ? (uint32_t)(kz == 2 ? 0 : kz + 1) * sc.nPrims * 3u : 0u;
@@ -192,7 +195,7 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
     if (!bounds_clip(sc, r, rayTMax, tMin, tMax)) return false;
 
     uint32_t privNode[RT_STACK_TOTAL - SL];
-    float privTMin[RT_STACK_TOTAL - SL], privTMax[RT_STACK_TOTAL - SL];
+    float privTMax[RT_STACK_TOTAL - SL];
     int sp = 0;
     uint32_t node = 0;
     bool found = false;
@@ -216,13 +219,11 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
                 node = second;
             } else {
                 if (sp < SL) {
-                    ldsStack[(sp * 3 + 0) * RT_BLOCK + tid] = second;
-                    ldsStack[(sp * 3 + 1) * RT_BLOCK + tid] = __float_as_uint(tPlane);
-                    ldsStack[(sp * 3 + 2) * RT_BLOCK + tid] = __float_as_uint(tMax);
+                    ldsStack[(sp * 2 + 0) * RT_BLOCK + tid] = second;
+                    ldsStack[(sp * 2 + 1) * RT_BLOCK + tid] = __float_as_uint(tMax);
                 } else {
                     const int q = sp - SL;
                     privNode[q] = second;
-                    privTMin[q] = tPlane;
                     privTMax[q] = tMax;
                 }
                 ++sp;
@@ -259,14 +260,13 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
         }
         if (sp == 0) break;
         --sp;
+        tMin = tMax;   // the segment after the one just finished starts where that one ended
         if (sp < SL) {
-            node = ldsStack[(sp * 3 + 0) * RT_BLOCK + tid];
-            tMin = __uint_as_float(ldsStack[(sp * 3 + 1) * RT_BLOCK + tid]);
-            tMax = __uint_as_float(ldsStack[(sp * 3 + 2) * RT_BLOCK + tid]);
+            node = ldsStack[(sp * 2 + 0) * RT_BLOCK + tid];
+            tMax = __uint_as_float(ldsStack[(sp * 2 + 1) * RT_BLOCK + tid]);
         } else {
             const int q = sp - SL;
             node = privNode[q];
-            tMin = privTMin[q];
             tMax = privTMax[q];
         }
     }

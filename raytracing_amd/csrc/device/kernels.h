@@ -42,8 +42,8 @@ RT_DEV void flush_counters(unsigned long long *stats, const TravCounters &cn, ui
     atomicAdd(&stats[ST_COUNTED_RAYS], (unsigned long long)rays);
 }
 
-// Dynamic LDS layout of every tracing kernel: [todo stack: LDS_N*3*RT_BLOCK dwords][scene tables]
-template <bool LDS_SCENE> RT_HD constexpr uint32_t stack_lds_bytes() { return StackCfg<LDS_SCENE>::LDS_N * 3 * RT_BLOCK * 4; }
+// Dynamic LDS layout of every tracing kernel: [todo stack: LDS_N*2*RT_BLOCK dwords][scene tables]
+template <bool LDS_SCENE> RT_HD constexpr uint32_t stack_lds_bytes() { return StackCfg<LDS_SCENE>::LDS_N * 2 * RT_BLOCK * 4; }
 
 // Dynamic LDS layout of the streaming kernels: [todo stack][prepared-ray pool: RT_POOL_BYTES][scene tables]
 template <bool LDS_SCENE> RT_HD constexpr uint32_t stream_lds_bytes() { return stack_lds_bytes<LDS_SCENE>() + RT_POOL_BYTES; }
@@ -298,6 +298,41 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
     }
 }
 
+// Streaming flavour of k_extend, used for scenes whose tables live in HBM: there a ray costs a hundred dependent
+// node fetches and the gap between the slowest and the average lane of a wave is what bounds the kernel.
+struct ExtendJob {
+    const float4 *rayA, *rayB;
+    float4 *hit;
+    RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
+        const float4 a = rayA[j], b = rayB[j];
+        ro = mk3(a.x, a.y, a.z);
+        rd = mk3(a.w, b.x, b.y);
+        tm = RT_INF;
+        return true;
+    }
+    RT_DEV void finish(uint32_t j, const HitRec &h) const { hit[j] = make_float4(__int_as_float(h.prim), h.b0, h.b1, h.b2); }
+};
+
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_stream(DevScene sc, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
+                                                            float4 *__restrict__ hit, const uint32_t *__restrict__ count,
+                                                            unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    const uint32_t n = *count;
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
+    TravCounters cn = {0, 0, 0, 0, 0};
+    ExtendJob job = {rayA, rayB, hit};
+    trace_stream<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
+                                                                      job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+        atomicAdd(&stats[ST_EXTEND_RAYS], (unsigned long long)n);
+    }
+}
+
 // One bounce of PathRenderer::Li (Render/Render.cpp:363-445) for every live path, after its closest hit
 // is known: emission, light sampling with MIS (uniformSampleOneLight / estimateDirect, :189-312), BSDF
 // sampling, Russian roulette. Visibility is resolved by k_shadow / k_probe afterwards.
@@ -486,6 +521,41 @@ RT_DEV void shadow_entries(const DevScene &sc, const SceneTables &tb, uint32_t *
     }
     if (STATS) flush_counters(stats, cn, myRays);
     if (block == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
+}
+
+struct ShadowJob {
+    const float4 *shA, *shB, *shC;
+    float4 *L;
+    RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
+        const float4 a = shA[j], b = shB[j];
+        ro = mk3(a.x, a.y, a.z);
+        rd = mk3(a.w, b.x, b.y);
+        tm = 1 - RT_SHADOW_EPS;
+        return true;
+    }
+    RT_DEV void finish(uint32_t j, const HitRec &h) const {
+        if (h.prim >= 0) return;   // occluded
+        const float4 b = shB[j], c = shC[j];
+        const uint32_t pathId = __float_as_uint(b.z);
+        float4 L4 = L[pathId];
+        L4.x += b.w; L4.y += c.x; L4.z += c.y;
+        L[pathId] = L4;
+    }
+};
+
+template <bool LDS_SCENE, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_stream(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    const uint32_t n = pb.counts[cnt_index(bounce, 1)];
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
+    TravCounters cn = {0, 0, 0, 0, 0};
+    ShadowJob job = {pb.shA, pb.shB, pb.shC, pb.L};
+    trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
+                                                                       job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }
 
 // Paths whose BSDF sample may see the chosen light (estimateDirect, Render/Render.cpp:266-310): resolve the

@@ -46,7 +46,7 @@ struct rt_context {
 
     // stats
     unsigned long long *dStats = nullptr;
-    int traceSchedule = RT_SCHEDULE_LOCKSTEP;
+    int traceSchedule = RT_SCHEDULE_AUTO;
     std::vector<EventPair> extendEvents;
     size_t extendEventsUsed = 0;
     double renderMs = 0;
@@ -234,6 +234,10 @@ void launch_stream(rt_context *c, bool stats, void (*kLdsStats)(KArgs...), void 
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, args...);
 }
 
+bool use_stream_schedule(const rt_context *c) {
+    return c->traceSchedule == RT_SCHEDULE_STREAM || (c->traceSchedule == RT_SCHEDULE_AUTO && !c->ldsScene);
+}
+
 // The streaming kernels index rays with 32 bits: larger batches are cut into several launches.
 constexpr uint64_t kMaxRaysPerLaunch = 1ull << 31;
 
@@ -244,7 +248,7 @@ int trace_closest_dev(rt_context *c, uint64_t n, const float *o, const float *d,
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
         int32_t *prim_ = prim ? prim + base : nullptr;
         float *t_ = t ? t + base : nullptr, *bary_ = bary ? bary + 3 * base : nullptr;
-        if (c->traceSchedule == RT_SCHEDULE_STREAM) {
+        if (use_stream_schedule(c)) {
             launch_stream(c, stats, k_trace_closest_stream<true, true>, k_trace_closest_stream<true, false>, k_trace_closest_stream<false, true>,
                           k_trace_closest_stream<false, false>, m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
         } else {
@@ -260,7 +264,7 @@ int trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, con
     for (uint64_t base = 0; base < n; base += kMaxRaysPerLaunch) {
         const uint64_t m = std::min<uint64_t>(kMaxRaysPerLaunch, n - base);
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
-        if (c->traceSchedule == RT_SCHEDULE_STREAM) {
+        if (use_stream_schedule(c)) {
             launch_stream(c, stats, k_trace_any_stream<true, true>, k_trace_any_stream<true, false>, k_trace_any_stream<false, true>,
                           k_trace_any_stream<false, false>, m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
         } else {
@@ -307,8 +311,12 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     if ((rc = ensure_path_buffers(c, nPix * (uint64_t)sppPass, p->max_depth))) return rc;
     if ((rc = ensure_spill(c))) return rc;
     const bool stats = p->collect_stats != 0;
-    const size_t lds = trace_lds_bytes(c);
+    const size_t lds = trace_lds_bytes(c), ldsStream = stream_lds_bytes_of(c);
     const int grid = c->gridBlocks;
+    // scenes in HBM: the extend and shadow kernels regroup rays inside the wave (dstream.h); their static work split
+    // assumes a resident grid, so the passes then run one after the other instead of on two overlapping streams
+    const bool streamTrace = use_stream_schedule(c);
+    const int pipesInUse = (streamTrace || std::getenv("RT_AMD_SINGLE_PIPE")) ? 1 : rt_context::kPipes;
 
     // the pipelines start after everything already queued on the context's stream
     HIPCHK(c, hipEventRecord(c->mainReady, c->stream));
@@ -316,7 +324,6 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     int lastPipe = -1;
     int passIndex = 0;
     for (int s0 = p->spp_begin; s0 < p->spp_end; s0 += sppPass, ++passIndex) {
-        static const int pipesInUse = std::getenv("RT_AMD_SINGLE_PIPE") ? 1 : rt_context::kPipes;   // profiling aid: kernels run one at a time
         const int k = passIndex % pipesInUse;
         PathBuffers &pb = c->pb[k];
         hipStream_t st = c->pipeStream[k];
@@ -335,7 +342,11 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
             const int cur = b & 1;
             EventPair *ep = next_event_pair(c);
             if (ep) HIPCHK(c, hipEventRecord(ep->a, st));
-            {
+            if (streamTrace) {
+                auto kx = stats ? k_extend_stream<false, true> : k_extend_stream<false, false>;
+                hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, (const float4 *)pb.rayA[cur],
+                                   (const float4 *)pb.rayB[cur], pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
+            } else {
                 auto kx = c->ldsScene ? (stats ? k_extend<true, true> : k_extend<true, false>) : (stats ? k_extend<false, true> : k_extend<false, false>);
                 hipLaunchKernelGGL(kx, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, (const float4 *)pb.rayA[cur], (const float4 *)pb.rayB[cur], pb.hit,
                                    (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
@@ -343,8 +354,13 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
             if (ep) HIPCHK(c, hipEventRecord(ep->b, st));
             hipLaunchKernelGGL(c->allLambert ? k_shade<MATSET_LAMBERT> : k_shade<MATSET_ANY>, dim3(grid), dim3(RT_BLOCK), 0, st, c->sc, cam, ps, pb, b);
             if (b < p->max_depth) {
-                auto ks = c->ldsScene ? (stats ? k_shadow<true, true> : k_shadow<true, false>) : (stats ? k_shadow<false, true> : k_shadow<false, false>);
-                hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
+                if (streamTrace) {
+                    auto ks = stats ? k_shadow_stream<false, true> : k_shadow_stream<false, false>;
+                    hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, pb, b, c->dStats);
+                } else {
+                    auto ks = c->ldsScene ? (stats ? k_shadow<true, true> : k_shadow<true, false>) : (stats ? k_shadow<false, true> : k_shadow<false, false>);
+                    hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
+                }
                 auto kp = c->ldsScene ? (stats ? k_probe<true, true> : k_probe<true, false>) : (stats ? k_probe<false, true> : k_probe<false, false>);
                 hipLaunchKernelGGL(kp, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
             }
@@ -722,7 +738,7 @@ void *rt_stream(rt_context *c) { return c ? (void *)c->stream : nullptr; }
 int rt_set_option(rt_context *c, int option, int value) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (option == RT_OPTION_TRACE_SCHEDULE) {
-        if (value != RT_SCHEDULE_LOCKSTEP && value != RT_SCHEDULE_STREAM) return fail(c, RT_ERR_INVALID_ARG, "unknown trace schedule");
+        if (value != RT_SCHEDULE_AUTO && value != RT_SCHEDULE_LOCKSTEP && value != RT_SCHEDULE_STREAM) return fail(c, RT_ERR_INVALID_ARG, "unknown trace schedule");
         c->traceSchedule = value;
         return RT_OK;
     }

@@ -170,9 +170,10 @@ class Context:
                          kw.get("rr_threshold", 1.0))
         self._check(self._lib.rt_render_dev(self._h, C.byref(p), rgb_ptr, weight_ptr))
 
-    def set_trace_schedule(self, stream):
-        """Batch tracers: False = one ray per lane (default), True = lanes take new rays as they finish."""
-        self._check(self._lib.rt_set_option(self._h, 1, 1 if stream else 0))
+    def set_trace_schedule(self, schedule):
+        """Ray-to-lane schedule: "auto" (default), "lockstep" (one ray per lane) or "stream" (lanes take new rays as they finish)."""
+        value = {"auto": 0, "lockstep": 1, "stream": 2}[schedule]
+        self._check(self._lib.rt_set_option(self._h, 1, value))
 
     def synchronize(self):
         self._check(self._lib.rt_synchronize(self._h))

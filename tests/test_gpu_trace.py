@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["lockstep", "stream"])
 def trace_schedule(request, gpu_ctx):
     """Every test of this module runs under both ray-to-lane schedules of the batch tracers."""
-    gpu_ctx.set_trace_schedule(request.param == "stream")
+    gpu_ctx.set_trace_schedule(request.param)
     yield request.param
-    gpu_ctx.set_trace_schedule(False)
+    gpu_ctx.set_trace_schedule("auto")
 
 
 def _compare_closest(ctx, orc, o, d, tmax=None, label=""):

@@ -46,7 +46,7 @@ def main():
         d = d.contiguous()
         torch.cuda.synchronize()
         for stream in (False, True):
-            ctx.set_trace_schedule(stream)
+            ctx.set_trace_schedule("stream" if stream else "lockstep")
             run1(name + (" stream" if stream else " lockstep"), o, d)
 
     def run1(name, o, d):
