@@ -57,6 +57,15 @@ typedef struct rt_light {
     int32_t two_sided; /* m_twoSided */
 } rt_light;
 
+/* ASphereShape (Shape/SphereShape.h:11-37): radius in object space plus the owning Entity's transforms
+ * (m_objectToWorld and its inverse, Object/Entity.cpp:69-70), column-major as glm stores them. */
+typedef struct rt_sphere {
+    int32_t prim_id;             /* index into the primitive list; shape_type[prim_id] must be RT_SHAPE_SPHERE */
+    float radius;
+    float object_to_world[16];
+    float world_to_object[16];
+} rt_sphere;
+
 /*
  * Flattened scene. The KD-tree arrays are the reference's own, verbatim
  * (KdTree::m_nodes / m_hitableIndices / m_bounds, Accelerators/KDTree.h:40-45):
@@ -75,7 +84,7 @@ typedef struct rt_scene_desc {
     float bounds[6];             /* pMin.xyz, pMax.xyz */
     uint32_t n_prims;
     const uint8_t *shape_type;   /* n_prims, RT_SHAPE_*; NULL = all triangles */
-    const float *tri_p;          /* n_prims * 9: p0, p1, p2 */
+    const float *tri_p;          /* n_prims * 9: p0, p1, p2 (ignored for spheres) */
     const float *tri_n;          /* n_prims * 9: n0, n1, n2 or NULL when no primitive has normals */
     const uint8_t *tri_has_n;    /* n_prims or NULL (= all have normals iff tri_n != NULL) */
     const float *tri_uv;         /* n_prims * 6 or NULL: default (0,0),(1,0),(1,1) (TriangleShape.cpp:396-401) */
@@ -85,6 +94,8 @@ typedef struct rt_scene_desc {
     const rt_material *materials;
     uint32_t n_lights;
     const rt_light *lights;      /* order = Scene::m_lights (Scene/SceneParser.cpp:166-172) */
+    uint32_t n_spheres;          /* one entry per primitive whose shape_type is RT_SHAPE_SPHERE */
+    const rt_sphere *spheres;
 } rt_scene_desc;
 
 enum { RT_INTEGRATOR_PATH = 0, RT_INTEGRATOR_WHITTED = 1 };
@@ -152,7 +163,8 @@ int rt_set_camera(rt_context *ctx, const float raster_to_camera[16], const float
 /* Closest hit: KdTree::hit(ray, isect) (Accelerators/KDTree.cpp:385-490) over n rays. d is used as
  * given (callers pass the normalised direction a reference Ray holds, Utils/Math.h:326-327).
  * Outputs: prim_id (-1 = miss), t (= ray.m_tMax after the call), bary (b0,b1,b2 of
- * Shape/TriangleShape.cpp:361-363). Any output pointer may be NULL. */
+ * Shape/TriangleShape.cpp:361-363; for a sphere hit (t, 0, 0): ASphereShape::hit, Shape/SphereShape.cpp:167-235, has
+ * no barycentrics). Any output pointer may be NULL. */
 int rt_trace_closest(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d_xyz,
                      const float *tmax, int32_t *prim_id, float *t, float *bary3);
 /* Any hit: KdTree::hit(ray) (Accelerators/KDTree.cpp:284-383). occluded[i] = 1 when something is hit. */

@@ -157,7 +157,15 @@ struct SurfaceInteraction : Interaction {
     float b[3] = {0, 0, 0};
 };
 
+// ASphereShape: radius and the entity's transform pair, column-major (glm)
+struct SphereRec {
+    float radius;
+    float o2w[16], w2o[16];
+};
+
 struct Scene {
+    std::vector<int32_t> sphereOf;      // per primitive: index into spheres, or -1 for a triangle
+    std::vector<SphereRec> spheres;
     std::vector<uint32_t> nodes;
     std::vector<int32_t> leafIdx;
     vec3 bmin, bmax;
@@ -184,6 +192,15 @@ struct Scene {
 struct Counters {
     uint64_t interior = 0, leaf = 0, leafIdx = 0, tri = 0, rays = 0, maxStack = 0;
 };
+
+// Transform::operator()(Vec3, w) (Utils/Transform.h:75-88); glm's mat4 * vec4 sums (c0 x + c1 y) + (c2 z + c3 w)
+vec3 xfApply(const float m[16], const vec3 &p, float w) {
+    float r[4];
+    for (int k = 0; k < 4; ++k) r[k] = (m[0 * 4 + k] * p.x + m[1 * 4 + k] * p.y) + (m[2 * 4 + k] * p.z + m[3 * 4 + k] * w);
+    if (w == 0.f) return vec3(r[0], r[1], r[2]);
+    if (r[3] == 1) return vec3(r[0], r[1], r[2]);
+    return vec3(r[0], r[1], r[2]) / r[3];
+}
 
 // ------------------------------------------------------------------------------------------------
 // triangle (Shape/TriangleShape.cpp)
@@ -290,10 +307,79 @@ bool triSurface(const Scene &s, int prim, const Ray &ray, const float b[3], Surf
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// sphere (Shape/SphereShape.cpp). No reference output exists for a scene with spheres: this part of the
+// oracle is a restatement read off the source only (parity unpinned).
+// ------------------------------------------------------------------------------------------------
+std::atomic<int> g_trigMode{0};
+inline float trigCos(float x) { return g_trigMode.load(std::memory_order_relaxed) ? (float)std::cos((double)x) : std::cos(x); }
+inline float trigSin(float x) { return g_trigMode.load(std::memory_order_relaxed) ? (float)std::sin((double)x) : std::sin(x); }
+inline float trigAcos(float x) { return g_trigMode.load(std::memory_order_relaxed) ? (float)std::acos((double)x) : std::acos(x); }
+
+// Quadratic of both hit flavours (:129-165, :167-200). rayObj = worldToObject(ray): Transform::operator()(Ray)
+// (Utils/Transform.h:90-97) builds a new Ray, whose constructor normalises the direction again.
+bool sphereTest(const SphereRec &sp, const Ray &r, Ray &rayObj, float &tHit) {
+    rayObj = Ray(xfApply(sp.w2o, r.o, 1.0f), xfApply(sp.w2o, r.d, 0.0f), r.tMax);
+    float a = dot(rayObj.d, rayObj.d);
+    float b = dot(rayObj.o, rayObj.d);
+    float c = dot(rayObj.o, rayObj.o) - sp.radius * sp.radius;
+    float discriminant = b * b - a * c;
+    if (discriminant <= 0) return false;
+    float discr_sqrt = std::sqrt(discriminant);
+    float t0 = (-b - discr_sqrt) / a;
+    float t1 = (-b + discr_sqrt) / a;
+    if (t0 > t1) std::swap(t0, t1);
+    if (t0 > rayObj.tMax || t1 <= 0) return false;
+    float tShapeHit = t0;
+    if (tShapeHit <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit > rayObj.tMax) return false;
+    }
+    tHit = tShapeHit;
+    return true;
+}
+
+// Surface part of ASphereShape::hit(ray, tHit, isect) (:202-234) + Transform::operator()(SurfaceInteraction)
+// (Utils/Transform.cpp:97-114). phi / u / v are not evaluated: nothing reads the uv of a sphere hit.
+void sphereSurface(const SphereRec &sp, const Ray &rayObj, float t, SurfaceInteraction &isect) {
+    const float radius = sp.radius;
+    vec3 pHit = rayObj.o + rayObj.d * t;
+    pHit = pHit * (radius / length(pHit - vec3(0, 0, 0)));
+    if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
+    float cz = pHit.z / radius;
+    cz = cz < -1 ? -1.f : (cz > 1 ? 1.f : cz);
+    float theta = trigAcos(cz);
+    float zRadius = std::sqrt(pHit.x * pHit.x + pHit.y * pHit.y);
+    float invZRadius = 1 / zRadius;
+    float cosPhi = pHit.x * invZRadius;
+    float sinPhi = pHit.y * invZRadius;
+    vec3 dpdu(-2 * kPi * pHit.y, 2 * kPi * pHit.x, 0);
+    vec3 dpdv = (2 * kPi) * vec3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * trigSin(theta));
+    // SurfaceInteraction(pHit, uv, -ray.direction(), dpdu, dpdv)
+    vec3 nObj = normalize(cross(dpdu, dpdv));
+    vec3 woObj = normalize(-rayObj.d);
+    isect.p = xfApply(sp.o2w, pHit, 1.0f);
+    isect.n = normalize(xfApply(sp.o2w, nObj, 0.0f));
+    isect.wo = normalize(xfApply(sp.o2w, woObj, 0.0f));
+    isect.dpdu = xfApply(sp.o2w, dpdu, 0.0f);
+    isect.dpdv = xfApply(sp.o2w, dpdv, 0.0f);
+    isect.n = faceforward(isect.n, isect.wo);
+}
+
 // HitableObject::hit(ray, isect) (Object/Hitable.cpp:21-30)
 bool primHit(const Scene &s, int prim, const Ray &ray, SurfaceInteraction &isect, Counters *cn) {
     if (cn) ++cn->tri;
     float t, b[3];
+    if (!s.sphereOf.empty() && s.sphereOf[prim] >= 0) {
+        const SphereRec &sp = s.spheres[s.sphereOf[prim]];
+        Ray rayObj;
+        if (!sphereTest(sp, ray, rayObj, t)) return false;
+        sphereSurface(sp, rayObj, t, isect);
+        isect.prim = prim;
+        isect.b[0] = t; isect.b[1] = 0; isect.b[2] = 0;   // what the batch interface reports for a sphere
+        ray.tMax = t;
+        return true;
+    }
     if (!triTest(s, prim, ray, t, b)) return false;
     if (!triSurface(s, prim, ray, b, isect)) return false;
     ray.tMax = t;
@@ -302,6 +388,10 @@ bool primHit(const Scene &s, int prim, const Ray &ray, SurfaceInteraction &isect
 bool primHitAny(const Scene &s, int prim, const Ray &ray, Counters *cn) {
     if (cn) ++cn->tri;
     float t, b[3];
+    if (!s.sphereOf.empty() && s.sphereOf[prim] >= 0) {
+        Ray rayObj;
+        return sphereTest(s.spheres[s.sphereOf[prim]], ray, rayObj, t);
+    }
     return triTest(s, prim, ray, t, b);
 }
 
@@ -441,10 +531,6 @@ bool kdHitAny(const Scene &s, const Ray &ray, Counters *cn) {
 // 0: libm cosf/sinf, as the reference calls them through glm (implementation-defined last bits: glibc's differ
 // from the correctly rounded value for ~1.3 % of arguments). 1: cos/sin evaluated in double and rounded once to
 // float, i.e. correctly rounded — what the HIP kernels compute — so that GPU and oracle agree bit for bit.
-std::atomic<int> g_trigMode{0};
-inline float trigCos(float x) { return g_trigMode.load(std::memory_order_relaxed) ? (float)std::cos((double)x) : std::cos(x); }
-inline float trigSin(float x) { return g_trigMode.load(std::memory_order_relaxed) ? (float)std::sin((double)x) : std::sin(x); }
-
 void concentricSampleDisk(const float u[2], float out[2]) {
     float ox = 2.f * u[0] - 1, oy = 2.f * u[1] - 1;
     if (ox == 0 && oy == 0) { out[0] = 0; out[1] = 0; return; }
@@ -652,8 +738,66 @@ Interaction triSample(const Scene &s, int prim, float area, const float u[2], fl
     pdf = 1 / area;
     return it;
 }
+// ASphereShape::sample(u, pdf) (SphereShape.cpp:28-40) with uniformSampleSphere (Render/Sampler.cpp:91-97)
+Interaction sphereSampleArea(const SphereRec &sp, float area, const float u[2], float &pdf) {
+    float z = 1 - 2 * u[0];
+    float r = std::sqrt(gmax((float)0, (float)1 - z * z));
+    float phi = 2 * kPi * u[1];
+    vec3 pObj = vec3(0, 0, 0) + sp.radius * vec3(r * trigCos(phi), r * trigSin(phi), z);
+    Interaction it;
+    it.n = normalize(xfApply(sp.o2w, pObj, 0.0f));
+    pObj = pObj * (sp.radius / length(pObj - vec3(0, 0, 0)));
+    it.p = xfApply(sp.o2w, pObj, 1.0f);
+    pdf = 1 / area;
+    return it;
+}
+// ASphereShape::sample(ref, u, pdf) (SphereShape.cpp:42-113)
+Interaction sphereSample(const SphereRec &sp, float area, const Interaction &ref, const float u[2], float &pdf) {
+    vec3 pCenter = xfApply(sp.o2w, vec3(0, 0, 0), 1.0f);
+    vec3 dc0 = ref.p - pCenter;
+    if (dot(dc0, dc0) <= sp.radius * sp.radius) {
+        Interaction intr = sphereSampleArea(sp, area, u, pdf);
+        vec3 wi = intr.p - ref.p;
+        if (dot(wi, wi) == 0) pdf = 0;
+        else {
+            wi = normalize(wi);
+            vec3 dd = ref.p - intr.p;
+            pdf *= dot(dd, dd) / absDot(intr.n, -wi);
+        }
+        if (std::isinf(pdf)) pdf = 0.f;
+        return intr;
+    }
+    float dc = length(ref.p - pCenter);
+    float invDc = 1 / dc;
+    vec3 wc = (pCenter - ref.p) * invDc;
+    vec3 wcX, wcY;
+    coordinateSystem(wc, wcX, wcY);
+    float sinThetaMax = sp.radius * invDc;
+    float sinThetaMax2 = sinThetaMax * sinThetaMax;
+    float invSinThetaMax = 1 / sinThetaMax;
+    float cosThetaMax = std::sqrt(gmax((float)0.f, 1.0f - sinThetaMax2));
+    float cosTheta = (cosThetaMax - 1) * u[0] + 1;
+    float sinTheta2 = 1 - cosTheta * cosTheta;
+    if (sinThetaMax2 < 0.00068523f) {
+        sinTheta2 = sinThetaMax2 * u[0];
+        cosTheta = std::sqrt(1 - sinTheta2);
+    }
+    float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * std::sqrt(gmax((float)0.f, 1.f - sinTheta2 * invSinThetaMax * invSinThetaMax));
+    float sinAlpha = std::sqrt(gmax((float)0.f, 1.f - cosAlpha * cosAlpha));
+    float phi = u[1] * 2 * kPi;
+    // sphericalDirection(sinAlpha, cosAlpha, phi, -wcX, -wcY, -wc) (Utils/Math.h:468-472)
+    vec3 nWorld = (sinAlpha * trigCos(phi)) * (-wcX) + (sinAlpha * trigSin(phi)) * (-wcY) + cosAlpha * (-wc);
+    vec3 pWorld = pCenter + sp.radius * vec3(nWorld.x, nWorld.y, nWorld.z);
+    Interaction it;
+    it.p = pWorld;
+    it.n = nWorld;
+    pdf = 1 / (2 * kPi * (1 - cosThetaMax));
+    return it;
+}
+
 // Shape::sample(ref, u, pdf)
 Interaction shapeSample(const Scene &s, int prim, float area, const Interaction &ref, const float u[2], float &pdf) {
+    if (!s.sphereOf.empty() && s.sphereOf[prim] >= 0) return sphereSample(s.spheres[s.sphereOf[prim]], area, ref, u, pdf);
     Interaction intr = triSample(s, prim, area, u, pdf);
     vec3 wi = intr.p - ref.p;
     if (dot(wi, wi) == 0) pdf = 0;
@@ -680,8 +824,23 @@ float lightPdfLi(const Scene &s, int lid, const Interaction &ref, const vec3 &wi
     Ray ray = ref.spawnRay(wi);
     SurfaceInteraction isectLight;
     float t, b[3];
-    if (!triTest(s, l.prim_id, ray, t, b)) return 0;
-    if (!triSurface(s, l.prim_id, ray, b, isectLight)) return 0;
+    if (!s.sphereOf.empty() && s.sphereOf[l.prim_id] >= 0) {
+        // ASphereShape::pdf (SphereShape.cpp:115-127)
+        const SphereRec &sp = s.spheres[s.sphereOf[l.prim_id]];
+        vec3 pCenter = xfApply(sp.o2w, vec3(0, 0, 0), 1.0f);
+        vec3 dc = ref.p - pCenter;
+        if (!(dot(dc, dc) <= sp.radius * sp.radius)) {
+            float sinThetaMax2 = sp.radius * sp.radius / dot(dc, dc);
+            float cosThetaMax = std::sqrt(gmax((float)0, 1 - sinThetaMax2));
+            return 1 / (2 * kPi * (1 - cosThetaMax));   // uniformConePdf
+        }
+        Ray rayObj;
+        if (!sphereTest(sp, ray, rayObj, t)) return 0;
+        sphereSurface(sp, rayObj, t, isectLight);
+    } else {
+        if (!triTest(s, l.prim_id, ray, t, b)) return 0;
+        if (!triSurface(s, l.prim_id, ray, b, isectLight)) return 0;
+    }
     vec3 dd = ref.p - isectLight.p;
     float pdf = dot(dd, dd) / (absDot(isectLight.n, -wi) * s.lightArea[lid]);
     if (std::isinf(pdf)) pdf = 0.f;
@@ -854,13 +1013,6 @@ Spectrum whittedLi(const Scene &s, const Ray &ray, Sampler &sampler, int maxDept
 // ------------------------------------------------------------------------------------------------
 // camera + film (Camera/Camera.cpp:87-95, Utils/Transform.h:75-97, Object/Film.h:111-155)
 // ------------------------------------------------------------------------------------------------
-vec3 xfApply(const float m[16], const vec3 &p, float w) {
-    float r[4];
-    for (int k = 0; k < 4; ++k) r[k] = (m[0 * 4 + k] * p.x + m[1 * 4 + k] * p.y) + (m[2 * 4 + k] * p.z + m[3 * 4 + k] * w);
-    if (w == 0.f) return vec3(r[0], r[1], r[2]);
-    if (r[3] == 1) return vec3(r[0], r[1], r[2]);
-    return vec3(r[0], r[1], r[2]) / r[3];
-}
 Ray cameraRay(const Scene &s, float fx, float fy) {
     vec3 pCamera = xfApply(s.r2c, vec3(fx, fy, 0), 1.0f);
     Ray ray(vec3(0, 0, 0), normalize(pCamera));
@@ -905,7 +1057,27 @@ oracle_scene *oracle_create(const rt_scene_desc *d) {
     s.lightId.assign(d->light_id, d->light_id + d->n_prims);
     s.materials.assign(d->materials, d->materials + d->n_materials);
     if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
-    for (auto &l : s.lights) s.lightArea.push_back(triArea(s, l.prim_id));
+    if (d->n_spheres) {
+        s.sphereOf.assign(d->n_prims, -1);
+        for (uint32_t i = 0; i < d->n_spheres; ++i) {
+            const rt_sphere &sp = d->spheres[i];
+            if (sp.prim_id < 0 || (uint32_t)sp.prim_id >= d->n_prims) { delete o; return nullptr; }
+            SphereRec r;
+            r.radius = sp.radius;
+            std::memcpy(r.o2w, sp.object_to_world, 64);
+            std::memcpy(r.w2o, sp.world_to_object, 64);
+            s.sphereOf[sp.prim_id] = (int)s.spheres.size();
+            s.spheres.push_back(r);
+        }
+    }
+    for (auto &l : s.lights) {
+        if (!s.sphereOf.empty() && s.sphereOf[l.prim_id] >= 0) {
+            const float r = s.spheres[s.sphereOf[l.prim_id]].radius;
+            s.lightArea.push_back(4.0f * kPi * r * r);   // ASphereShape::area (SphereShape.cpp:26)
+        } else {
+            s.lightArea.push_back(triArea(s, l.prim_id));
+        }
+    }
     // UniformLightDistribution + Distribution1D (Utils/LightDistrib.cpp:17-21, LightDistrib.h:14-33)
     int n = (int)s.lights.size();
     if (n > 0) {

@@ -18,6 +18,10 @@ class RtLight(C.Structure):
     _fields_ = [("prim_id", C.c_int32), ("emit", C.c_float * 3), ("two_sided", C.c_int32)]
 
 
+class RtSphere(C.Structure):
+    _fields_ = [("prim_id", C.c_int32), ("radius", C.c_float), ("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16)]
+
+
 class RtSceneDesc(C.Structure):
     _fields_ = [
         ("n_nodes", C.c_uint32),
@@ -37,6 +41,8 @@ class RtSceneDesc(C.Structure):
         ("materials", C.POINTER(RtMaterial)),
         ("n_lights", C.c_uint32),
         ("lights", C.POINTER(RtLight)),
+        ("n_spheres", C.c_uint32),
+        ("spheres", C.POINTER(RtSphere)),
     ]
 
 

@@ -22,6 +22,7 @@ RT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 RT_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_HD float absdot3(f3 a, f3 b) { return fabsf(dot3(a, b)); }
 RT_HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+RT_HD float length3(f3 a) { return sqrtf(dot3(a, a)); }   // glm::length
 RT_HD f3 normalize3(f3 a) { return a * (1.0f / sqrtf(dot3(a, a))); }
 RT_HD float gmin(float x, float y) { return (y < x) ? y : x; }   // glm::min: NaN handling differs from fminf
 RT_HD float gmax(float x, float y) { return (x < y) ? y : x; }   // glm::max
@@ -102,3 +103,40 @@ RT_HD void sincos_disk(float theta, float &s, float &c) {
     s = (float)(upper ? cr : sr);
     c = (float)(upper ? -sr : cr);
 }
+
+// sin and cos of any angle in [-2 pi, 2 pi], same evaluation (quadrant reduction with a two-part pi/2, then the
+// polynomials above): used where the reference calls sinf / cosf on an azimuth or a polar angle.
+RT_HD void sincos_cr(float theta, float &s, float &c) {
+    const double t = (double)theta;
+    const double kd = __builtin_rint(t * 0.63661977236758134308);   // t / (pi/2)
+    const int k = (int)kd;
+    double r = (t - kd * 1.57079632679489655800e+00) - kd * 6.12323399573676603587e-17;
+    double r2 = r * r;
+    double sp = -2.8114572543455206e-15;
+    sp = __builtin_fma(sp, r2, 7.6471637318198164e-13);
+    sp = __builtin_fma(sp, r2, -1.6059043836821613e-10);
+    sp = __builtin_fma(sp, r2, 2.5052108385441720e-08);
+    sp = __builtin_fma(sp, r2, -2.7557319223985893e-06);
+    sp = __builtin_fma(sp, r2, 1.9841269841269841e-04);
+    sp = __builtin_fma(sp, r2, -8.3333333333333332e-03);
+    sp = __builtin_fma(sp, r2, 1.6666666666666666e-01);
+    const double sr = r - r * r2 * sp;
+    double cp = 4.7794773323873853e-14;
+    cp = __builtin_fma(cp, r2, -1.1470745597729725e-11);
+    cp = __builtin_fma(cp, r2, 2.0876756987868100e-09);
+    cp = __builtin_fma(cp, r2, -2.7557319223985888e-07);
+    cp = __builtin_fma(cp, r2, 2.4801587301587302e-05);
+    cp = __builtin_fma(cp, r2, -1.3888888888888889e-03);
+    cp = __builtin_fma(cp, r2, 4.1666666666666664e-02);
+    cp = __builtin_fma(cp, r2, -0.5);
+    const double cr = __builtin_fma(cp, r2, 1.0);
+    const int q = k & 3;
+    const double sv = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
+    const double cv = (q == 0) ? cr : (q == 1) ? -sr : (q == 2) ? -cr : sr;
+    s = (float)sv;
+    c = (float)cv;
+}
+
+// acos rounded once from double (the reference calls acosf on the cosine of a sphere hit's polar angle).
+RT_HD float acos_cr(float x) { return (float)acos((double)x); }
+

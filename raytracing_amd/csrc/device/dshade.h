@@ -20,8 +20,50 @@ struct Surf {
     int mat, light;
 };
 
-RT_DEV void surface_at(const DevScene &sc, int prim, float b0, float b1, float b2, Surf &s) {
+// Surface part of ASphereShape::hit(ray, tHit, isect) (Shape/SphereShape.cpp:202-234) followed by
+// Transform::operator()(SurfaceInteraction) (Utils/Transform.cpp:97-114), from the object-space ray and t.
+// phi, u and v are not evaluated: nothing reads the uv of a sphere hit. Returns p, n (faced towards wo) and
+// ss = normalize(dpdu) in world space.
+RT_DEV void sphere_surface(const DevSphere &sp, f3 oObj, f3 dObj, float t, f3 &p, f3 &n, f3 &ss) {
+    const float radius = sp.radius;
+    f3 pHit = oObj + dObj * t;
+    pHit = pHit * (radius / length3(pHit - mk3(0.f, 0.f, 0.f)));
+    if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
+    float cz = pHit.z / radius;
+    cz = cz < -1 ? -1.f : (cz > 1 ? 1.f : cz);
+    const float theta = acos_cr(cz);
+    const float zRadius = sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
+    const float invZRadius = 1 / zRadius;
+    const float cosPhi = pHit.x * invZRadius;
+    const float sinPhi = pHit.y * invZRadius;
+    float sinTheta, cosTheta;
+    sincos_cr(theta, sinTheta, cosTheta);
+    const f3 dpdu = mk3(-2 * RT_PI * pHit.y, 2 * RT_PI * pHit.x, 0.f);
+    const f3 dpdv = (2 * RT_PI) * mk3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * sinTheta);
+    const f3 nObj = normalize3(cross3(dpdu, dpdv));
+    const f3 woObj = normalize3(-dObj);
+    p = xf_apply(sp.o2w, pHit, 1.0f);
+    n = normalize3(xf_apply(sp.o2w, nObj, 0.0f));
+    const f3 wo = normalize3(xf_apply(sp.o2w, woObj, 0.0f));
+    ss = normalize3(xf_apply(sp.o2w, dpdu, 0.0f));
+    if (dot3(n, wo) < 0.f) n = -n;   // faceforward(isect.n, isect.wo)
+}
+
+// Rebuilds the surface at a hit. (ro, rd) is the ray that was traced (needed for spheres, whose hit record holds
+// t in b0); triangles use the barycentrics only.
+template <bool SPH>
+RT_DEV void surface_at(const DevScene &sc, int prim, float b0, float b1, float b2, f3 ro, f3 rd, Surf &s) {
     const float4 q0 = sc.triHot[3 * prim + 0], q1 = sc.triHot[3 * prim + 1], q2 = sc.triHot[3 * prim + 2];
+    if (SPH && q0.w == RT_PRIM_SPHERE) {
+        const DevSphere &sp = sc.spheres[__float_as_int(q0.x)];
+        const f3 oObj = xf_apply(sp.w2o, ro, 1.0f);
+        const f3 dObj = normalize3(xf_apply(sp.w2o, rd, 0.0f));
+        sphere_surface(sp, oObj, dObj, b0, s.p, s.n, s.ss);
+        const float4 s4 = sc.triShade[5 * prim + 4];
+        s.mat = __float_as_int(s4.x);
+        s.light = __float_as_int(s4.y);
+        return;
+    }
     const float4 s0 = sc.triShade[5 * prim + 0], s1 = sc.triShade[5 * prim + 1], s2 = sc.triShade[5 * prim + 2];
     const float4 s3 = sc.triShade[5 * prim + 3], s4 = sc.triShade[5 * prim + 4];
     s.p = b0 * mk3(q0.x, q0.y, q0.z) + b1 * mk3(q1.x, q1.y, q1.z) + b2 * mk3(q2.x, q2.y, q2.z);
@@ -236,23 +278,89 @@ RT_DEV int sample_light(const DevScene &sc, float u, float &pdf) {
     return offset;
 }
 
-// DiffuseAreaLight::sample_Li for a triangle light. Returns Li; pdf = 0 means no sample.
+// RT_DEV coordinateSystem (Utils/Math.h:454-461)
+RT_DEV void coordinate_system(f3 v1, f3 &v2, f3 &v3) {
+    if (fabsf(v1.x) > fabsf(v1.y)) v2 = mk3(-v1.z, 0.f, v1.x) / sqrtf(v1.x * v1.x + v1.z * v1.z);
+    else v2 = mk3(0.f, v1.z, -v1.y) / sqrtf(v1.y * v1.y + v1.z * v1.z);
+    v3 = cross3(v1, v2);
+}
+
+// ASphereShape::sample(ref, u, pdf) (Shape/SphereShape.cpp:42-113): uniform over the cone the sphere subtends, or
+// uniform over the area (ASphereShape::sample(u, pdf), :28-40) when the reference point is inside.
+RT_DEV void sphere_sample(const DevSphere &sp, float area, f3 refP, float u0, float u1, f3 &p, f3 &n, float &pdf) {
+    const f3 pCenter = xf_apply(sp.o2w, mk3(0.f, 0.f, 0.f), 1.0f);
+    const f3 dc0 = refP - pCenter;
+    if (dot3(dc0, dc0) <= sp.radius * sp.radius) {
+        const float z = 1 - 2 * u0;
+        const float r = sqrtf(gmax(0.f, 1.f - z * z));
+        const float phi = 2 * RT_PI * u1;
+        float sphi, cphi;
+        sincos_cr(phi, sphi, cphi);
+        f3 pObj = mk3(0.f, 0.f, 0.f) + sp.radius * mk3(r * cphi, r * sphi, z);
+        n = normalize3(xf_apply(sp.o2w, pObj, 0.0f));
+        pObj = pObj * (sp.radius / length3(pObj - mk3(0.f, 0.f, 0.f)));
+        p = xf_apply(sp.o2w, pObj, 1.0f);
+        pdf = 1 / area;
+        f3 w = p - refP;
+        if (dot3(w, w) == 0) pdf = 0;
+        else {
+            w = normalize3(w);
+            const f3 dd = refP - p;
+            pdf *= dot3(dd, dd) / absdot3(n, -w);
+        }
+        if (isinf(pdf)) pdf = 0.f;
+        return;
+    }
+    const float dc = length3(refP - pCenter);
+    const float invDc = 1 / dc;
+    const f3 wc = (pCenter - refP) * invDc;
+    f3 wcX, wcY;
+    coordinate_system(wc, wcX, wcY);
+    const float sinThetaMax = sp.radius * invDc;
+    const float sinThetaMax2 = sinThetaMax * sinThetaMax;
+    const float invSinThetaMax = 1 / sinThetaMax;
+    const float cosThetaMax = sqrtf(gmax(0.f, 1.0f - sinThetaMax2));
+    float cosTheta = (cosThetaMax - 1) * u0 + 1;
+    float sinTheta2 = 1 - cosTheta * cosTheta;
+    if (sinThetaMax2 < 0.00068523f) {
+        sinTheta2 = sinThetaMax2 * u0;
+        cosTheta = sqrtf(1 - sinTheta2);
+    }
+    const float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * sqrtf(gmax(0.f, 1.f - sinTheta2 * invSinThetaMax * invSinThetaMax));
+    const float sinAlpha = sqrtf(gmax(0.f, 1.f - cosAlpha * cosAlpha));
+    const float phi = u1 * 2 * RT_PI;
+    float sphi, cphi;
+    sincos_cr(phi, sphi, cphi);
+    // sphericalDirection(sinAlpha, cosAlpha, phi, -wcX, -wcY, -wc) (Utils/Math.h:468-472)
+    const f3 nWorld = (sinAlpha * cphi) * (-wcX) + (sinAlpha * sphi) * (-wcY) + cosAlpha * (-wc);
+    p = pCenter + sp.radius * mk3(nWorld.x, nWorld.y, nWorld.z);
+    n = nWorld;
+    pdf = 1 / (2 * RT_PI * (1 - cosThetaMax));
+}
+
+// DiffuseAreaLight::sample_Li for a triangle or sphere light. Returns Li; pdf = 0 means no sample.
 // pShape receives the sampled point (the shadow ray's target).
+template <bool SPH>
 RT_DEV f3 light_sample_Li(const DevScene &sc, const DevLight &l, f3 refP, float u0, float u1, f3 &wi, float &pdf, f3 &pShape) {
     const float4 q0 = sc.triHot[3 * l.prim + 0], q1 = sc.triHot[3 * l.prim + 1], q2 = sc.triHot[3 * l.prim + 2];
-    const f3 p0 = mk3(q0.x, q0.y, q0.z), p1 = mk3(q1.x, q1.y, q1.z), p2 = mk3(q2.x, q2.y, q2.z);
-    const float su0 = sqrtf(u0);
-    const float b0 = 1 - su0, b1 = u1 * su0;
-    const f3 p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
-    const f3 n = normalize3(cross3(p1 - p0, p2 - p0));
-    pdf = 1 / l.area;
-    f3 w = p - refP;
-    if (dot3(w, w) == 0) pdf = 0;
-    else {
-        w = normalize3(w);
-        const f3 dd = refP - p;
-        pdf *= dot3(dd, dd) / absdot3(n, -w);
-        if (isinf(pdf)) pdf = 0.f;
+    f3 p, n;
+    if (SPH && q0.w == RT_PRIM_SPHERE) {
+        sphere_sample(sc.spheres[__float_as_int(q0.x)], l.area, refP, u0, u1, p, n, pdf);
+    } else {
+        const f3 p0 = mk3(q0.x, q0.y, q0.z), p1 = mk3(q1.x, q1.y, q1.z), p2 = mk3(q2.x, q2.y, q2.z);
+        const float su0 = sqrtf(u0);
+        const float b0 = 1 - su0, b1 = u1 * su0;
+        p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+        n = normalize3(cross3(p1 - p0, p2 - p0));
+        pdf = 1 / l.area;
+        f3 w = p - refP;
+        if (dot3(w, w) == 0) pdf = 0;
+        else {
+            w = normalize3(w);
+            const f3 dd = refP - p;
+            pdf *= dot3(dd, dd) / absdot3(n, -w);
+            if (isinf(pdf)) pdf = 0.f;
+        }
     }
     const f3 d2 = p - refP;
     if (pdf == 0 || dot3(d2, d2) == 0) { pdf = 0; return mk3(0.f, 0.f, 0.f); }
@@ -262,15 +370,33 @@ RT_DEV f3 light_sample_Li(const DevScene &sc, const DevLight &l, f3 refP, float 
 }
 
 // DiffuseAreaLight::pdf_Li -> Shape::pdf(ref, wi): one closest-flavour triangle test against the light's shape.
+template <bool SPH>
 RT_DEV float light_pdf_Li(const DevScene &sc, const DevLight &l, f3 refP, f3 wi) {
-    RayCtx r;
-    ray_setup(r, refP, normalize3(wi));
     const float4 q0 = sc.triHot[3 * l.prim + 0], q1 = sc.triHot[3 * l.prim + 1], q2 = sc.triHot[3 * l.prim + 2];
-    float t, b0, b1, b2;
-    if (!tri_test<false>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), RT_INF, t, b0, b1, b2)) return 0;
-    if (q0.w != 0.f) return 0;
+    const f3 rd = normalize3(wi);   // Interaction::spawnRay -> Ray constructor
     Surf s;
-    surface_at(sc, l.prim, b0, b1, b2, s);
+    if (SPH && q0.w == RT_PRIM_SPHERE) {
+        // ASphereShape::pdf (Shape/SphereShape.cpp:115-127)
+        const DevSphere &sp = sc.spheres[__float_as_int(q0.x)];
+        const f3 pCenter = xf_apply(sp.o2w, mk3(0.f, 0.f, 0.f), 1.0f);
+        const f3 dc = refP - pCenter;
+        if (!(dot3(dc, dc) <= sp.radius * sp.radius)) {
+            const float sinThetaMax2 = sp.radius * sp.radius / dot3(dc, dc);
+            const float cosThetaMax = sqrtf(gmax(0.f, 1 - sinThetaMax2));
+            return 1 / (2 * RT_PI * (1 - cosThetaMax));   // uniformConePdf
+        }
+        f3 oObj, dObj;
+        float t;
+        if (!sphere_test(sp, refP, rd, RT_INF, oObj, dObj, t)) return 0;
+        sphere_surface(sp, oObj, dObj, t, s.p, s.n, s.ss);
+    } else {
+        RayCtx r;
+        ray_setup(r, refP, rd);
+        float t, b0, b1, b2;
+        if (!tri_test<false>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), RT_INF, t, b0, b1, b2)) return 0;
+        if (q0.w != 0.f) return 0;
+        surface_at<false>(sc, l.prim, b0, b1, b2, refP, rd, s);
+    }
     const f3 dd = refP - s.p;
     float pdf = dot3(dd, dd) / (absdot3(s.n, -wi) * l.area);
     if (isinf(pdf)) pdf = 0.f;

@@ -36,7 +36,7 @@
 #define RT_POOL_BYTES (RT_BLOCK * RT_POOL_VEC_PER_RAY * 16)     // per workgroup: 64 prepared rays per wave
 
 // Prepared ray in the pool: {o, d.x} {d.yz, invDir.xy} {invDir.z, Sx, Sy, Sz} {tMin, tMax, rayTMax, job}
-template <bool CLOSEST, bool STATS, int SL, bool PERM, class Job>
+template <bool CLOSEST, bool STATS, int SL, bool PERM, bool SPH, class Job>
 RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ldsStack, uint4 *ldsPool, uint32_t n, Job &job, TravCounters &cn) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -218,12 +218,21 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                 const float4 q2 = tb.triHot[triBase + 3 * prim + 2];
                 float t, b0, b1, b2;
                 ++leafI;
-                if (tri_test<PERM>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2)) {
+                bool accepted;
+                if (SPH && q0.w == RT_PRIM_SPHERE) {
+                    f3 oo, dd;
+                    accepted = sphere_test(sc.spheres[__float_as_int(q0.x)], r.o, r.d, rayTMax, oo, dd, t);
+                    b0 = t;
+                    b1 = b2 = 0.f;
+                } else {
+                    accepted = tri_test<PERM>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2);
+                }
+                if (accepted) {
                     if (!CLOSEST) {
                         hit.prim = prim;
                         job.finish(jobId, hit);
                         active = false;
-                    } else if (q0.w == 0.f) {   // not degenerate
+                    } else if (q0.w != RT_PRIM_DEGENERATE) {
                         rayTMax = t;
                         hit.prim = prim;
                         hit.t = t;

@@ -35,6 +35,15 @@ struct DevLight {
     float pad0, pad1;
 };
 
+// ASphereShape: the entity's transform pair (column-major) and the radius. A sphere primitive's triHot record is
+// {bits(sphere index) x3, 2.0f}: the w of p0 tells the traversal which test to run.
+struct DevSphere {
+    float w2o[16], o2w[16];
+    float radius, pad0, pad1, pad2;
+};
+#define RT_PRIM_DEGENERATE 1.f
+#define RT_PRIM_SPHERE 2.f
+
 // Device scene: separate tables per access pattern. Records are 16-byte multiples so a lane's gather
 // is one or a few dwordx4 loads.
 //   nodes     uint2  per node   {split | onePrim | indexOffset, axis/leaf flag | child or count << 2}
@@ -54,6 +63,7 @@ struct DevScene {
     const DevLight *lights;
     const float *lightCdf;    // nLights + 1
     const float *lightFunc;   // nLights
+    const DevSphere *spheres;
     float bmin[3], bmax[3];
     uint32_t nNodes, nLeafIdx, nPrims, nMats, nLights;
     float lightFuncInt;
@@ -162,6 +172,42 @@ RT_DEV bool tri_test(const RayCtx &r, f3 p0, f3 p1, f3 p2, float rayTMax, float 
     return true;
 }
 
+// Transform::operator()(Vec3, w) (Utils/Transform.h:75-88); glm's mat4 * vec4 sums (c0 x + c1 y) + (c2 z + c3 w).
+RT_DEV f3 xf_apply(const float *m, f3 p, float w) {
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (m[0 * 4 + k] * p.x + m[1 * 4 + k] * p.y) + (m[2 * 4 + k] * p.z + m[3 * 4 + k] * w);
+    if (w == 0.f) return mk3(r[0], r[1], r[2]);
+    if (r[3] == 1) return mk3(r[0], r[1], r[2]);
+    return mk3(r[0], r[1], r[2]) / r[3];
+}
+
+// The quadratic of ASphereShape::hit, both flavours (Shape/SphereShape.cpp:129-200). The ray goes to object space
+// through Transform::operator()(Ray) (Utils/Transform.h:90-97), whose Ray constructor normalises the direction again.
+RT_DEV bool sphere_test(const DevSphere &sp, f3 o, f3 d, float rayTMax, f3 &oObj, f3 &dObj, float &tHit) {
+    oObj = xf_apply(sp.w2o, o, 1.0f);
+    dObj = normalize3(xf_apply(sp.w2o, d, 0.0f));
+    const float a = dot3(dObj, dObj);
+    const float b = dot3(oObj, dObj);
+    const float c = dot3(oObj, oObj) - sp.radius * sp.radius;
+    const float discriminant = b * b - a * c;
+    if (discriminant <= 0) return false;
+    const float sq = sqrtf(discriminant);
+    float t0 = (-b - sq) / a;
+    float t1 = (-b + sq) / a;
+    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0 > rayTMax || t1 <= 0) return false;
+    float tShapeHit = t0;
+    if (tShapeHit <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit > rayTMax) return false;
+    }
+    tHit = tShapeHit;
+    return true;
+}
+
+// Result of a traversal. For a triangle b0..b2 are the barycentrics; for a sphere b0 repeats t and b1 = b2 = 0
+// (the surface of a sphere hit is rebuilt from the ray and t).
 struct HitRec {
     int prim;
     float t, b0, b1, b2;
@@ -184,7 +230,8 @@ template <bool PERM> RT_DEV uint32_t tri_table_base(const DevScene &sc, int kz) 
     return PERM ? (uint32_t)(kz == 2 ? 0 : kz + 1) * sc.nPrims * 3u : 0u;
 }
 
-template <bool CLOSEST, bool STATS, int SL, bool PERM>
+// SPH: the scene has sphere primitives (scenes without them compile the sphere test away).
+template <bool CLOSEST, bool STATS, int SL, bool PERM, bool SPH>
 RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsStack, uint32_t tid, const RayCtx &r, float rayTMaxIn,
                      HitRec &hit, TravCounters &cn) {
     float tMin, tMax;
@@ -247,9 +294,18 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
             const float4 q1 = tris[3 * prim + 1];
             const float4 q2 = tris[3 * prim + 2];
             float t, b0, b1, b2;
-            if (tri_test<PERM>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2)) {
+            bool accepted;
+            if (SPH && q0.w == RT_PRIM_SPHERE) {
+                f3 oo, dd;
+                accepted = sphere_test(sc.spheres[__float_as_int(q0.x)], r.o, r.d, rayTMax, oo, dd, t);
+                b0 = t;
+                b1 = b2 = 0.f;
+            } else {
+                accepted = tri_test<PERM>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2);
+            }
+            if (accepted) {
                 if (!CLOSEST) { hit.prim = prim; return true; }
-                if (q0.w == 0.f) {   // not degenerate
+                if (q0.w != RT_PRIM_DEGENERATE) {
                     rayTMax = t;
                     hit.prim = prim;
                     hit.t = t;

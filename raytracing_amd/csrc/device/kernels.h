@@ -18,14 +18,6 @@ struct CameraDev {
     int sb[4];   // sample bounds x0,y0,x1,y1
 };
 
-RT_DEV f3 xf_apply(const float *m, f3 p, float w) {   // Transform::operator()(Vec3, w), Utils/Transform.h:75-88
-    float r[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = (m[0 * 4 + k] * p.x + m[1 * 4 + k] * p.y) + (m[2 * 4 + k] * p.z + m[3 * 4 + k] * w);
-    if (w == 0.f) return mk3(r[0], r[1], r[2]);
-    if (r[3] == 1) return mk3(r[0], r[1], r[2]);
-    return mk3(r[0], r[1], r[2]) / r[3];
-}
 // APerspectiveCamera::castingRay (Camera/Camera.cpp:87-95): three normalisations, as the reference's Ray constructor does.
 RT_DEV void camera_ray(const CameraDev &cam, float fx, float fy, f3 &o, f3 &d) {
     const f3 pCamera = xf_apply(cam.r2c, mk3(fx, fy, 0.f), 1.0f);
@@ -65,7 +57,7 @@ RT_DEV void tables_setup(const DevScene &sc, uint4 *smem, SceneTables &tb, uint3
 // Two schedules (rt_set_option RT_OPTION_TRACE_SCHEDULE). Lockstep: one ray per lane, the wave waits for its
 // slowest lane; best for coherent batches (camera rays) and small batches. Streaming (dstream.h): lanes take
 // new rays as they finish; best for large batches of incoherent rays.
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                             const float *__restrict__ tmax, int *__restrict__ prim, float *__restrict__ tOut,
                                                             float *__restrict__ bary, unsigned long long *stats) {
@@ -79,7 +71,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_
         RayCtx r;
         ray_setup(r, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
         HitRec h;
-        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
+        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
         if (prim) prim[i] = h.prim;
         if (tOut) tOut[i] = h.t;
         if (bary) { bary[3 * i] = h.b0; bary[3 * i + 1] = h.b1; bary[3 * i + 2] = h.b2; }
@@ -89,7 +81,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
 }
 
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                         const float *__restrict__ tmax, uint8_t *__restrict__ occluded, unsigned long long *stats) {
     extern __shared__ uint4 smem[];
@@ -102,7 +94,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DevScene sc, uint64_t n,
         RayCtx r;
         ray_setup(r, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
         HitRec h;
-        const bool hit = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
+        const bool hit = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, tmax ? tmax[i] : RT_INF, h, cn);
         occluded[i] = hit ? 1 : 0;
         ++myRays;
     }
@@ -143,7 +135,7 @@ struct TraceAnyJob {
 };
 
 // Streaming flavours. n < 2^32 (the host splits larger batches); the grid must be resident as a whole.
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_stream(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                                    const float *__restrict__ tmax, int *__restrict__ prim, float *__restrict__ tOut,
                                                                    float *__restrict__ bary, unsigned long long *stats) {
@@ -152,13 +144,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_stream(DevScene sc, 
     tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
     TravCounters cn = {0, 0, 0, 0, 0};
     TraceClosestJob job = {o, d, tmax, prim, tOut, bary};
-    trace_stream<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16,
+    trace_stream<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16,
                                                                       (uint32_t)n, job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
 }
 
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_any_stream(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                                const float *__restrict__ tmax, uint8_t *__restrict__ occluded, unsigned long long *stats) {
     extern __shared__ uint4 smem[];
@@ -166,7 +158,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any_stream(DevScene sc, uint
     tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
     TravCounters cn = {0, 0, 0, 0, 0};
     TraceAnyJob job = {o, d, tmax, occluded};
-    trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16,
+    trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16,
                                                                        (uint32_t)n, job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
@@ -271,7 +263,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(CameraDev cam, PassInfo ps,
     }
 }
 
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
                                                      float4 *__restrict__ hit, const uint32_t *__restrict__ count, unsigned long long *stats) {
     extern __shared__ uint4 smem[];
@@ -287,7 +279,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
         RayCtx r;
         ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
         HitRec h;
-        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+        kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
         hit[i] = make_float4(__int_as_float(h.prim), h.b0, h.b1, h.b2);
         ++myRays;
     }
@@ -313,7 +305,7 @@ struct ExtendJob {
     RT_DEV void finish(uint32_t j, const HitRec &h) const { hit[j] = make_float4(__int_as_float(h.prim), h.b0, h.b1, h.b2); }
 };
 
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_stream(DevScene sc, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
                                                             float4 *__restrict__ hit, const uint32_t *__restrict__ count,
                                                             unsigned long long *stats) {
@@ -324,7 +316,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_stream(DevScene sc, const f
     tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
     TravCounters cn = {0, 0, 0, 0, 0};
     ExtendJob job = {rayA, rayB, hit};
-    trace_stream<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
+    trace_stream<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
                                                                       job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -336,7 +328,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_stream(DevScene sc, const f
 // One bounce of PathRenderer::Li (Render/Render.cpp:363-445) for every live path, after its closest hit
 // is known: emission, light sampling with MIS (uniformSampleOneLight / estimateDirect, :189-312), BSDF
 // sampling, Russian roulette. Visibility is resolved by k_shadow / k_probe afterwards.
-template <int MATSET>
+template <int MATSET, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev cam, PassInfo ps, PathBuffers pb, int bounce) {
     const int cur = bounce & 1, nxt = cur ^ 1;
     __shared__ uint32_t s_app[16];
@@ -365,7 +357,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
             alive = false;   // set again when the path continues
             if (prim >= 0) {
                 Surf sf;
-                surface_at(sc, prim, hr.y, hr.z, hr.w, sf);
+                surface_at<SPH>(sc, prim, hr.y, hr.z, hr.w, mk3(ra.x, ra.y, ra.z), rd, sf);
                 float4 L4 = pb.L[pathId];
                 float4 beta4 = pb.beta[pathId];
                 f3 beta = mk3(beta4.x, beta4.y, beta4.z);
@@ -398,7 +390,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
                             // estimateDirect, light-sampling half
                             f3 wi, pShape;
                             float lightPdf = 0, scatteringPdf = 0;
-                            f3 Li = light_sample_Li(sc, lt, sf.p, ul0, ul1, wi, lightPdf, pShape);
+                            f3 Li = light_sample_Li<SPH>(sc, lt, sf.p, ul0, ul1, wi, lightPdf, pShape);
                             f3 A = mk3(0.f, 0.f, 0.f);
                             bool haveShadow = false;
                             f3 shD = mk3(0.f, 0.f, 0.f);
@@ -424,7 +416,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
                                 if (!black3(f2) && pdfB > 0) {
                                     bool go = true;
                                     if (!sampledSpecular) {
-                                        const float lp = light_pdf_Li(sc, lt, sf.p, wi2);
+                                        const float lp = light_pdf_Li<SPH>(sc, lt, sf.p, wi2);
                                         if (lp == 0) go = false;
                                         else weightB = power_heuristic(pdfB, lp);
                                     }
@@ -500,7 +492,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
 
 // Shadow rays of the light-sampling half (VisibilityTester::unoccluded, Render/Light.cpp:28-31): any-hit
 // over Ray(p, pLight - p, 1 - ShadowEpsilon); a visible light adds its contribution to the path's L.
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 RT_DEV void shadow_entries(const DevScene &sc, const SceneTables &tb, uint32_t *stk, const PathBuffers &pb, uint32_t n, uint32_t block,
                            uint32_t nBlocks, unsigned long long *stats) {
     TravCounters cn = {0, 0, 0, 0};
@@ -510,7 +502,7 @@ RT_DEV void shadow_entries(const DevScene &sc, const SceneTables &tb, uint32_t *
         RayCtx r;
         ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
         HitRec h;
-        const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
+        const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
         if (!occluded) {
             const uint32_t pathId = __float_as_uint(b.z);
             float4 L4 = pb.L[pathId];
@@ -543,7 +535,7 @@ struct ShadowJob {
     }
 };
 
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow_stream(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
     extern __shared__ uint4 smem[];
     const uint32_t n = pb.counts[cnt_index(bounce, 1)];
@@ -552,7 +544,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_stream(DevScene sc, PathBuf
     tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
     TravCounters cn = {0, 0, 0, 0, 0};
     ShadowJob job = {pb.shA, pb.shB, pb.shC, pb.L};
-    trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
+    trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
                                                                        job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
@@ -561,7 +553,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_stream(DevScene sc, PathBuf
 // Paths whose BSDF sample may see the chosen light (estimateDirect, Render/Render.cpp:266-310): resolve the
 // shadow ray of the light sample (if any) and the closest hit along the BSDF sample, then add
 // beta * ((A' + B') / selPdf) to the path's L with the reference's association.
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 RT_DEV void probe_entries(const DevScene &sc, const SceneTables &tb, uint32_t *stk, const PathBuffers &pb, uint32_t n, uint32_t block,
                           uint32_t nBlocks, unsigned long long *stats) {
     TravCounters cn = {0, 0, 0, 0};
@@ -577,7 +569,7 @@ RT_DEV void probe_entries(const DevScene &sc, const SceneTables &tb, uint32_t *s
             RayCtx r;
             ray_setup(r, p, mk3(e1.x, e1.y, e1.z));
             HitRec h;
-            const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
+            const bool occluded = kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, 1 - RT_SHADOW_EPS, h, cn);
             if (!occluded) Ld = Ld + mk3(e2.x, e2.y, e2.z);
             ++myRays;
             ++nShadow;
@@ -587,12 +579,12 @@ RT_DEV void probe_entries(const DevScene &sc, const SceneTables &tb, uint32_t *s
             RayCtx r;
             ray_setup(r, p, normalize3(wi));
             HitRec h;
-            const bool found = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+            const bool found = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
             ++myRays;
             f3 Li = mk3(0.f, 0.f, 0.f);
             if (found) {
                 Surf sf;
-                surface_at(sc, h.prim, h.b0, h.b1, h.b2, sf);
+                surface_at<SPH>(sc, h.prim, h.b0, h.b1, h.b2, p, r.d, sf);
                 if (sf.light == li) Li = light_L(sc.lights[li], sf.n, -wi);
             }
             if (!black3(Li)) Ld = Ld + mk3(e4.x, e4.y, e4.z) * Li * mk3(1.f, 1.f, 1.f) * e3.w / e4.w;
@@ -607,24 +599,24 @@ RT_DEV void probe_entries(const DevScene &sc, const SceneTables &tb, uint32_t *s
     if (block == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
 }
 
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
     extern __shared__ uint4 smem[];
     const uint32_t n = pb.counts[cnt_index(bounce, 1)];
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
-    shadow_entries<LDS_SCENE, STATS>(sc, tb, reinterpret_cast<uint32_t *>(smem), pb, n, blockIdx.x, gridDim.x, stats);
+    shadow_entries<LDS_SCENE, STATS, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), pb, n, blockIdx.x, gridDim.x, stats);
 }
 
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
     extern __shared__ uint4 smem[];
     const uint32_t n = pb.counts[cnt_index(bounce, 2)];
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
-    probe_entries<LDS_SCENE, STATS>(sc, tb, reinterpret_cast<uint32_t *>(smem), pb, n, blockIdx.x, gridDim.x, stats);
+    probe_entries<LDS_SCENE, STATS, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), pb, n, blockIdx.x, gridDim.x, stats);
 }
 
 // Sample filter of the render loop (Render/Render.cpp:72-83).
@@ -711,7 +703,7 @@ struct WFrame {
     float absd, pdf;
     int prim;
     float b0, b1, b2;
-    f3 rd;
+    f3 ro, rd;
     int stage;
 };
 
@@ -720,7 +712,7 @@ struct WFrame {
 // (L += f * Li(child) * |wi.n| / pdf). The frame at stack position k is the call at recursion depth k.
 // When `countOnly` is set nothing is shaded: the function only consumes the random numbers the full
 // evaluation would consume (the specular tree does not depend on them).
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f3 ro, f3 rdir, Pcg &rng, int maxDepth, bool countOnly,
                      TravCounters &cn, uint32_t &nClosest, uint32_t &nAny) {
     WFrame fr[RT_WHITTED_MAX_FRAMES];
@@ -734,12 +726,12 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
             ray_setup(r, ro, rdir);
             HitRec h;
             ++nClosest;
-            const bool hit = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+            const bool hit = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
             Lret = mk3(0.f, 0.f, 0.f);
             state = RETURN;
             if (hit) {
                 Surf sf;
-                surface_at(sc, h.prim, h.b0, h.b1, h.b2, sf);
+                surface_at<SPH>(sc, h.prim, h.b0, h.b1, h.b2, ro, rdir, sf);
                 const f3 wo = normalize3(-rdir);
                 DBsdf bs;
                 bsdf_init<MATSET_ANY>(bs, sf, sc.mats[sf.mat]);
@@ -750,7 +742,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
                     if (countOnly) continue;
                     f3 wi, pShape;
                     float pdf;
-                    const f3 Li = light_sample_Li(sc, sc.lights[li], sf.p, u0, u1, wi, pdf, pShape);
+                    const f3 Li = light_sample_Li<SPH>(sc, sc.lights[li], sf.p, u0, u1, wi, pdf, pShape);
                     if (black3(Li) || pdf == 0) continue;
                     const f3 f = bsdf_f(bs, wo, wi, BSDF_ALL);
                     if (!black3(f)) {
@@ -758,7 +750,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
                         ray_setup(sr, sf.p, normalize3(pShape - sf.p));
                         HitRec sh;
                         ++nAny;
-                        if (!kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE>(sc, tb, stk, threadIdx.x, sr, 1 - RT_SHADOW_EPS, sh, cn))
+                        if (!kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, sr, 1 - RT_SHADOW_EPS, sh, cn))
                             L = L + f * Li * absdot3(wi, sf.n) / pdf;
                     }
                 }
@@ -766,6 +758,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
                     WFrame &f = fr[sp++];
                     f.L = L;
                     f.prim = h.prim; f.b0 = h.b0; f.b1 = h.b1; f.b2 = h.b2;
+                    f.ro = ro;
                     f.rd = rdir;
                     f.stage = 0;
                     f.pdf = 0.f;
@@ -784,7 +777,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
             }
             // stage 0: specularReflect, stage 1: specularTransmit
             Surf sf;
-            surface_at(sc, f.prim, f.b0, f.b1, f.b2, sf);
+            surface_at<SPH>(sc, f.prim, f.b0, f.b1, f.b2, f.ro, f.rd, sf);
             DBsdf bs;
             bsdf_init<MATSET_ANY>(bs, sf, sc.mats[sf.mat]);
             const f3 wo = normalize3(-f.rd);
@@ -815,7 +808,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
 // Reference tile stream, step 1: one lane per 16x16 tile walks the tile's samples in the reference's
 // order (Render/Render.cpp:32-92) consuming random numbers exactly as the full evaluation would, and
 // records the PCG32 state at the first sample of every pixel.
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_whitted_prepass(DevScene sc, CameraDev cam, int spp, int maxDepth, uint32_t nTiles, uint32_t ntx,
                                                               uint2 *pixelState) {
     extern __shared__ uint4 smem[];
@@ -839,14 +832,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted_prepass(DevScene sc, Camer
                 const float u0 = pcg_float(rng), u1 = pcg_float(rng);
                 f3 o, d;
                 camera_ray(cam, (float)x + u0, (float)y + u1, o, d);
-                whitted_li<LDS_SCENE, false>(sc, tb, stk, o, d, rng, maxDepth, true, cn, nc, na);
+                whitted_li<LDS_SCENE, false, SPH>(sc, tb, stk, o, d, rng, maxDepth, true, cn, nc, na);
             }
         }
 }
 
 // Step 2 (and the whole job in counter mode): one lane per pixel evaluates its samples in order and adds
 // them to the film.
-template <bool LDS_SCENE, bool STATS>
+template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam, int sppBegin, int sppEnd, int sppTotal, int maxDepth, int rngMode,
                                                       uint64_t seed, const uint2 *pixelState, float *rgbSum, float *weightSum, float *spillRgb,
                                                       float *spillW, unsigned long long *stats) {
@@ -882,7 +875,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam
             const float pfx = (float)px + u0, pfy = (float)py + u1;
             f3 o, d;
             camera_ray(cam, pfx, pfy, o, d);
-            f3 L = whitted_li<LDS_SCENE, STATS>(sc, tb, stk, o, d, rng, maxDepth, false, cn, nc, na);
+            f3 L = whitted_li<LDS_SCENE, STATS, SPH>(sc, tb, stk, o, d, rng, maxDepth, false, cn, nc, na);
             L = sanitize_L(L);
             ++ns;
             int fx0, fy0, fx1, fy1;

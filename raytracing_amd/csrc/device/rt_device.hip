@@ -35,8 +35,9 @@ struct rt_context {
     bool haveScene = false;
     DevScene sc{};
     void *dNodes = nullptr, *dLeafIdx = nullptr, *dTriHot = nullptr, *dTriShade = nullptr, *dMats = nullptr, *dLights = nullptr;
-    void *dLightCdf = nullptr, *dLightFunc = nullptr;
+    void *dLightCdf = nullptr, *dLightFunc = nullptr, *dSpheres = nullptr;
     bool ldsScene = false;
+    bool hasSpheres = false;
     bool hasGlass = false;
     bool allLambert = false;
 
@@ -86,7 +87,7 @@ int fail(rt_context *ctx, int code, const std::string &msg) {
 }
 
 void free_scene(rt_context *c) {
-    void **ptrs[] = {&c->dNodes, &c->dLeafIdx, &c->dTriHot, &c->dTriShade, &c->dMats, &c->dLights, &c->dLightCdf, &c->dLightFunc};
+    void **ptrs[] = {&c->dNodes, &c->dLeafIdx, &c->dTriHot, &c->dTriShade, &c->dMats, &c->dLights, &c->dLightCdf, &c->dLightFunc, &c->dSpheres};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -144,6 +145,13 @@ int upload(rt_context *c, void **dst, const std::vector<T> &v, size_t padBytes =
     if (bytes) HIPCHK(c, hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
     return RT_OK;
 }
+
+// Kernel variant for this context's scene: tables in LDS or HBM, traversal counters on or off, spheres or not.
+#define RT_PICK(K, c, stats)                                                                                                    \
+    ((c)->hasSpheres ? ((c)->ldsScene ? ((stats) ? K<true, true, true> : K<true, false, true>)                                  \
+                                      : ((stats) ? K<false, true, true> : K<false, false, true>))                               \
+                     : ((c)->ldsScene ? ((stats) ? K<true, true, false> : K<true, false, false>)                                \
+                                      : ((stats) ? K<false, true, false> : K<false, false, false>)))
 
 size_t trace_lds_bytes(const rt_context *c) { return c->ldsScene ? stack_lds_bytes<true>() + c->sc.ldsSceneBytes : stack_lds_bytes<false>(); }
 size_t stream_lds_bytes_of(const rt_context *c) { return c->ldsScene ? stream_lds_bytes<true>() + c->sc.ldsSceneBytes : stream_lds_bytes<false>(); }
@@ -217,18 +225,14 @@ int resident_grid(rt_context *c, K kernel, size_t ldsBytes) {
     return grid;
 }
 
-template <typename... KArgs, typename... Args>
-void launch_lockstep(rt_context *c, bool stats, void (*kLdsStats)(KArgs...), void (*kLds)(KArgs...), void (*kGlobStats)(KArgs...),
-                     void (*kGlob)(KArgs...), uint64_t n, Args... args) {
-    auto k = c->ldsScene ? (stats ? kLdsStats : kLds) : (stats ? kGlobStats : kGlob);
+template <typename K, typename... Args>
+void launch_lockstep(rt_context *c, K k, uint64_t n, Args... args) {
     const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)c->gridBlocks);
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), trace_lds_bytes(c), c->stream, args...);
 }
 
-template <typename... KArgs, typename... Args>
-void launch_stream(rt_context *c, bool stats, void (*kLdsStats)(KArgs...), void (*kLds)(KArgs...), void (*kGlobStats)(KArgs...),
-                   void (*kGlob)(KArgs...), uint64_t n, Args... args) {
-    auto k = c->ldsScene ? (stats ? kLdsStats : kLds) : (stats ? kGlobStats : kGlob);
+template <typename K, typename... Args>
+void launch_stream(rt_context *c, K k, uint64_t n, Args... args) {
     const size_t lds = stream_lds_bytes_of(c);
     const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)resident_grid(c, k, lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, args...);
@@ -249,11 +253,9 @@ int trace_closest_dev(rt_context *c, uint64_t n, const float *o, const float *d,
         int32_t *prim_ = prim ? prim + base : nullptr;
         float *t_ = t ? t + base : nullptr, *bary_ = bary ? bary + 3 * base : nullptr;
         if (use_stream_schedule(c)) {
-            launch_stream(c, stats, k_trace_closest_stream<true, true>, k_trace_closest_stream<true, false>, k_trace_closest_stream<false, true>,
-                          k_trace_closest_stream<false, false>, m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
+            launch_stream(c, RT_PICK(k_trace_closest_stream, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
         } else {
-            launch_lockstep(c, stats, k_trace_closest<true, true>, k_trace_closest<true, false>, k_trace_closest<false, true>,
-                            k_trace_closest<false, false>, m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
+            launch_lockstep(c, RT_PICK(k_trace_closest, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -265,11 +267,9 @@ int trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, con
         const uint64_t m = std::min<uint64_t>(kMaxRaysPerLaunch, n - base);
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
         if (use_stream_schedule(c)) {
-            launch_stream(c, stats, k_trace_any_stream<true, true>, k_trace_any_stream<true, false>, k_trace_any_stream<false, true>,
-                          k_trace_any_stream<false, false>, m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
+            launch_stream(c, RT_PICK(k_trace_any_stream, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
         } else {
-            launch_lockstep(c, stats, k_trace_any<true, true>, k_trace_any<true, false>, k_trace_any<false, true>, k_trace_any<false, false>, m,
-                            c->sc, m, o_, d_, tm_, occ + base, c->dStats);
+            launch_lockstep(c, RT_PICK(k_trace_any, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -343,25 +343,27 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
             EventPair *ep = next_event_pair(c);
             if (ep) HIPCHK(c, hipEventRecord(ep->a, st));
             if (streamTrace) {
-                auto kx = stats ? k_extend_stream<false, true> : k_extend_stream<false, false>;
+                auto kx = RT_PICK(k_extend_stream, c, stats);
                 hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, (const float4 *)pb.rayA[cur],
                                    (const float4 *)pb.rayB[cur], pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
             } else {
-                auto kx = c->ldsScene ? (stats ? k_extend<true, true> : k_extend<true, false>) : (stats ? k_extend<false, true> : k_extend<false, false>);
+                auto kx = RT_PICK(k_extend, c, stats);
                 hipLaunchKernelGGL(kx, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, (const float4 *)pb.rayA[cur], (const float4 *)pb.rayB[cur], pb.hit,
                                    (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
             }
             if (ep) HIPCHK(c, hipEventRecord(ep->b, st));
-            hipLaunchKernelGGL(c->allLambert ? k_shade<MATSET_LAMBERT> : k_shade<MATSET_ANY>, dim3(grid), dim3(RT_BLOCK), 0, st, c->sc, cam, ps, pb, b);
+            auto ksh = c->hasSpheres ? (c->allLambert ? k_shade<MATSET_LAMBERT, true> : k_shade<MATSET_ANY, true>)
+                                     : (c->allLambert ? k_shade<MATSET_LAMBERT, false> : k_shade<MATSET_ANY, false>);
+            hipLaunchKernelGGL(ksh, dim3(grid), dim3(RT_BLOCK), 0, st, c->sc, cam, ps, pb, b);
             if (b < p->max_depth) {
                 if (streamTrace) {
-                    auto ks = stats ? k_shadow_stream<false, true> : k_shadow_stream<false, false>;
+                    auto ks = RT_PICK(k_shadow_stream, c, stats);
                     hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, pb, b, c->dStats);
                 } else {
-                    auto ks = c->ldsScene ? (stats ? k_shadow<true, true> : k_shadow<true, false>) : (stats ? k_shadow<false, true> : k_shadow<false, false>);
+                    auto ks = RT_PICK(k_shadow, c, stats);
                     hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
                 }
-                auto kp = c->ldsScene ? (stats ? k_probe<true, true> : k_probe<true, false>) : (stats ? k_probe<false, true> : k_probe<false, false>);
+                auto kp = RT_PICK(k_probe, c, stats);
                 hipLaunchKernelGGL(kp, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
             }
         }
@@ -400,7 +402,8 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
             HIPCHK(c, hipMalloc((void **)&c->dPixelState, need * sizeof(uint2)));
             c->pixelStateCap = need;
         }
-        auto k = c->ldsScene ? k_whitted_prepass<true> : k_whitted_prepass<false>;
+        auto k = c->hasSpheres ? (c->ldsScene ? k_whitted_prepass<true, true> : k_whitted_prepass<false, true>)
+                               : (c->ldsScene ? k_whitted_prepass<true, false> : k_whitted_prepass<false, false>);
         // one lane per tile: spread the lanes over many small groups of waves
         hipLaunchKernelGGL(k, dim3((nTiles + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, c->stream, c->sc, cam, p->spp_total, p->max_depth,
                            nTiles, ntx, c->dPixelState);
@@ -408,7 +411,7 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
     }
     const uint32_t nSlots = nTiles * 256u;
     const int grid = (int)std::min<uint32_t>((nSlots + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)c->gridBlocks * 4u);
-    auto k = c->ldsScene ? (stats ? k_whitted<true, true> : k_whitted<true, false>) : (stats ? k_whitted<false, true> : k_whitted<false, false>);
+    auto k = RT_PICK(k_whitted, c, stats);
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, cam, p->spp_begin, p->spp_end, p->spp_total, p->max_depth, p->rng_mode,
                        p->seed, (const uint2 *)c->dPixelState, rgb, wsum, c->dSpillRgb, c->dSpillW, c->dStats);
     HIPCHK(c, hipGetLastError());
@@ -488,10 +491,24 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
         return fail(c, RT_ERR_INVALID_ARG, "scene description has NULL or empty required arrays");
     // validate everything a kernel will index with
     for (uint32_t i = 0; i < d->n_prims; ++i) {
-        if (d->shape_type && d->shape_type[i] != RT_SHAPE_TRIANGLE) return fail(c, RT_ERR_UNSUPPORTED, "only triangle shapes are supported");
+        if (d->shape_type && d->shape_type[i] != RT_SHAPE_TRIANGLE && d->shape_type[i] != RT_SHAPE_SPHERE)
+            return fail(c, RT_ERR_INVALID_ARG, "unknown shape type");
         if (d->material_id[i] < 0 || (uint32_t)d->material_id[i] >= d->n_materials) return fail(c, RT_ERR_INVALID_ARG, "material_id out of range");
         if (d->light_id[i] >= (int32_t)d->n_lights) return fail(c, RT_ERR_INVALID_ARG, "light_id out of range");
     }
+    // every sphere primitive needs exactly one rt_sphere record
+    std::vector<int32_t> sphereOf(d->n_prims, -1);
+    if (d->n_spheres && !d->spheres) return fail(c, RT_ERR_INVALID_ARG, "spheres is NULL");
+    for (uint32_t i = 0; i < d->n_spheres; ++i) {
+        const int32_t pid = d->spheres[i].prim_id;
+        if (pid < 0 || (uint32_t)pid >= d->n_prims || !d->shape_type || d->shape_type[pid] != RT_SHAPE_SPHERE || sphereOf[pid] >= 0)
+            return fail(c, RT_ERR_INVALID_ARG, "sphere record does not match a sphere primitive");
+        if (!(d->spheres[i].radius > 0)) return fail(c, RT_ERR_INVALID_ARG, "sphere radius must be positive");
+        sphereOf[pid] = (int32_t)i;
+    }
+    for (uint32_t i = 0; i < d->n_prims; ++i)
+        if (d->shape_type && d->shape_type[i] == RT_SHAPE_SPHERE && sphereOf[i] < 0)
+            return fail(c, RT_ERR_INVALID_ARG, "sphere primitive without an rt_sphere record");
     for (uint32_t i = 0; i < d->n_lights; ++i)
         if (d->lights[i].prim_id < 0 || (uint32_t)d->lights[i].prim_id >= d->n_prims) return fail(c, RT_ERR_INVALID_ARG, "light prim_id out of range");
     for (uint32_t i = 0; i < d->n_materials; ++i)
@@ -521,6 +538,19 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     const uint32_t triCopies = c->ldsScene ? 3u : 1u;
     std::vector<float4> hot((size_t)np * 3 * triCopies), shade((size_t)np * 5);
     for (uint32_t i = 0; i < np; ++i) {
+        if (sphereOf[i] >= 0) {
+            float bits, mi, li;
+            std::memcpy(&bits, &sphereOf[i], 4);
+            for (uint32_t b = 0; b < triCopies; ++b) {
+                hot[((size_t)b * np + i) * 3 + 0] = make_float4(bits, bits, bits, RT_PRIM_SPHERE);
+                hot[((size_t)b * np + i) * 3 + 1] = hot[((size_t)b * np + i) * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            for (int k = 0; k < 4; ++k) shade[5 * (size_t)i + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            std::memcpy(&mi, &d->material_id[i], 4);
+            std::memcpy(&li, &d->light_id[i], 4);
+            shade[5 * (size_t)i + 4] = make_float4(mi, li, 0.f, 0.f);
+            continue;
+        }
         const float *p = &d->tri_p[9 * (size_t)i];
         f3 ss, ng;
         bool degenerate;
@@ -555,6 +585,11 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     std::vector<DevLight> lights(d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const rt_light &l = d->lights[i];
+        if (sphereOf[l.prim_id] >= 0) {
+            const float r = d->spheres[sphereOf[l.prim_id]].radius;
+            lights[i] = DevLight{l.emit[0], l.emit[1], l.emit[2], l.two_sided, l.prim_id, 4.0f * RT_PI * r * r, 0.f, 0.f};   // ASphereShape::area
+            continue;
+        }
         const float *p = &d->tri_p[9 * (size_t)l.prim_id];
         const f3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
         const f3 cr = cross3(p1 - p0, p2 - p0);
@@ -584,6 +619,14 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     if ((rc = upload(c, &c->dLights, lights))) return rc;
     if ((rc = upload(c, &c->dLightCdf, cdf))) return rc;
     if ((rc = upload(c, &c->dLightFunc, func))) return rc;
+    std::vector<DevSphere> spheres(d->n_spheres);
+    for (uint32_t i = 0; i < d->n_spheres; ++i) {
+        std::memcpy(spheres[i].w2o, d->spheres[i].world_to_object, 64);
+        std::memcpy(spheres[i].o2w, d->spheres[i].object_to_world, 64);
+        spheres[i].radius = d->spheres[i].radius;
+        spheres[i].pad0 = spheres[i].pad1 = spheres[i].pad2 = 0.f;
+    }
+    if ((rc = upload(c, &c->dSpheres, spheres))) return rc;
 
     DevScene &sc = c->sc;
     sc.nodes = (const uint2 *)c->dNodes;
@@ -594,6 +637,8 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     sc.lights = (const DevLight *)c->dLights;
     sc.lightCdf = (const float *)c->dLightCdf;
     sc.lightFunc = (const float *)c->dLightFunc;
+    sc.spheres = (const DevSphere *)c->dSpheres;
+    c->hasSpheres = d->n_spheres > 0;
     for (int k = 0; k < 3; ++k) { sc.bmin[k] = d->bounds[k]; sc.bmax[k] = d->bounds[3 + k]; }
     sc.nNodes = d->n_nodes;
     sc.nLeafIdx = d->n_leaf_idx;
@@ -783,6 +828,9 @@ int rt_reset_stats(rt_context *c) {
 }
 
 // Host evaluation of the device's sin/cos for the concentric disk mapping, for CPU-side accuracy tests.
+// Host-side evaluation of the device's trigonometric helpers (they are __host__ __device__): lets a CPU test compare
+// them with a double-precision libm without a GPU.
 void rt_debug_sincos_disk(float theta, float *s, float *c) { sincos_disk(theta, *s, *c); }
+void rt_debug_sincos_cr(float theta, float *s, float *c) { sincos_cr(theta, *s, *c); }
 
 }  // extern "C"

@@ -156,6 +156,7 @@ struct rt_host_scene {
     std::vector<int32_t> material_id, light_id;
     std::vector<rt_material> materials;
     std::vector<rt_light> lights;
+    std::vector<rt_sphere> spheres;
     KdTreeFlat tree;
     rt_scene_desc desc{};
     rt_host_config cfg{};
@@ -168,6 +169,22 @@ struct rt_host_scene {
             const float *p = &tri_p[9 * i];
             pb[i] = box_union(box_of({p[0], p[1], p[2]}, {p[3], p[4], p[5]}), V3{p[6], p[7], p[8]});
         }
+        shape_type.assign(n, RT_SHAPE_TRIANGLE);
+        for (const rt_sphere &sp : spheres) {
+            // Shape::worldBound = objectToWorld(objectBound) (Shape/Shape.cpp:26, SphereShape.cpp:20-24, Utils/Transform.cpp:82-95)
+            shape_type[sp.prim_id] = RT_SHAPE_SPHERE;
+            const M4 m = load_m4(sp.object_to_world);
+            const float r = sp.radius;
+            const V3 lo{-r, -r, -r}, hi{r, r, r};
+            const V3 corner[8] = {{lo.x, lo.y, lo.z}, {hi.x, lo.y, lo.z}, {lo.x, hi.y, lo.z}, {lo.x, lo.y, hi.z},
+                                  {lo.x, hi.y, hi.z}, {hi.x, hi.y, lo.z}, {hi.x, lo.y, hi.z}, {hi.x, hi.y, hi.z}};
+            const V3 first = xf_apply(m, corner[0], 1.0f);
+            Box3 b;
+            b.pMin = first;   // BBox3(p): both corners are the point
+            b.pMax = first;
+            for (int k = 1; k < 8; ++k) b = box_union(b, xf_apply(m, corner[k], 1.0f));
+            pb[sp.prim_id] = b;
+        }
         kd_build(pb, tree);
         desc.n_nodes = (uint32_t)(tree.nodes.size() / 2);
         desc.nodes = tree.nodes.data();
@@ -176,7 +193,8 @@ struct rt_host_scene {
         desc.bounds[0] = tree.bounds.pMin.x; desc.bounds[1] = tree.bounds.pMin.y; desc.bounds[2] = tree.bounds.pMin.z;
         desc.bounds[3] = tree.bounds.pMax.x; desc.bounds[4] = tree.bounds.pMax.y; desc.bounds[5] = tree.bounds.pMax.z;
         desc.n_prims = (uint32_t)n;
-        shape_type.assign(n, RT_SHAPE_TRIANGLE);
+        desc.n_spheres = (uint32_t)spheres.size();
+        desc.spheres = spheres.empty() ? nullptr : spheres.data();
         desc.shape_type = shape_type.data();
         desc.tri_p = tri_p.data();
         desc.tri_n = tri_n.empty() ? nullptr : tri_n.data();
@@ -263,8 +281,7 @@ static void load_json_impl(const std::string &path, rt_host_scene &S) {
     for (const JsonValue &e : ej->arr) {
         Props ep(&e);
         std::string etype = ep.getString("Type");
-        if (etype != "MeshEntity")
-            throw std::runtime_error("entity type \"" + etype + "\" (analytic shapes) is not supported by this front-end yet");
+        if (etype != "MeshEntity" && etype != "Entity") throw std::runtime_error("unknown entity type \"" + etype + "\"");
         Props shape(ep.child("Shape"));
         Xf o2w = parse_transform(shape);
         Props mp(ep.child("Material"));
@@ -289,6 +306,28 @@ static void load_json_impl(const std::string &path, rt_host_scene &S) {
             light.two_sided = lp.getBoolean("TwoSided", false) ? 1 : 0;
         }
 
+        if (etype == "Entity") {
+            // Entity (reference src/core/Object/Entity.cpp:11-87): one analytic shape, here ASphereShape (SphereShape.cpp:12-15)
+            const std::string stype = shape.getString("Type");
+            if (stype != "Sphere") throw std::runtime_error("Entity shape \"" + stype + "\" is not a shape of the reference");
+            rt_sphere sp{};
+            sp.prim_id = (int)S.material_id.size();
+            sp.radius = shape.getFloat("Radius", 1.0f);
+            store_m4(o2w.m, sp.object_to_world);
+            store_m4(o2w.inv, sp.world_to_object);   // inverse(Transform) swaps the pair (Utils/Transform.h)
+            S.spheres.push_back(sp);
+            for (int k = 0; k < 9; ++k) { S.tri_p.push_back(0.f); S.tri_n.push_back(0.f); }
+            S.tri_has_n.push_back(0);
+            S.material_id.push_back(matId);
+            if (lj) {
+                light.prim_id = sp.prim_id;
+                S.light_id.push_back((int)S.lights.size());
+                S.lights.push_back(light);
+            } else {
+                S.light_id.push_back(-1);
+            }
+            continue;
+        }
         ImportedMesh mesh;
         import_obj(dir + ep.getString("Filename"), mesh);
         if (!mesh.uv.empty()) throw std::runtime_error("OBJ files with texture coordinates are not supported by this front-end yet");

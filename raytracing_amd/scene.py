@@ -11,7 +11,7 @@ from typing import Optional
 
 import numpy as np
 
-from ._ctypes_defs import (RtHostConfig, RtHostTreeStats, RtLight, RtMaterial, RtSceneDesc)
+from ._ctypes_defs import (RtHostConfig, RtHostTreeStats, RtLight, RtMaterial, RtSceneDesc, RtSphere)
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 _host = None
@@ -103,7 +103,10 @@ def develop(rgb_sum, weight_sum, film_scale=1.0):
 
 _MAT_DTYPE = np.dtype([("type", np.int32), ("rgb", np.float32, 3), ("eta", np.float32)])
 _LIGHT_DTYPE = np.dtype([("prim_id", np.int32), ("emit", np.float32, 3), ("two_sided", np.int32)])
+_SPHERE_DTYPE = np.dtype([("prim_id", np.int32), ("radius", np.float32), ("object_to_world", np.float32, 16),
+                          ("world_to_object", np.float32, 16)])
 assert _MAT_DTYPE.itemsize == C.sizeof(RtMaterial) and _LIGHT_DTYPE.itemsize == C.sizeof(RtLight)
+assert _SPHERE_DTYPE.itemsize == C.sizeof(RtSphere)
 
 
 @dataclass
@@ -119,6 +122,14 @@ class FlatScene:
     lights: np.ndarray        # structured (_LIGHT_DTYPE)
     config: Optional[RenderConfig] = None
     tree_stats: Optional[dict] = None
+    spheres: Optional[np.ndarray] = None   # structured (_SPHERE_DTYPE); primitives listed here are spheres
+
+    @property
+    def shape_type(self):
+        st = np.zeros(self.n_prims, np.uint8)
+        if self.spheres is not None and len(self.spheres):
+            st[self.spheres["prim_id"]] = 1
+        return st
 
     @property
     def n_prims(self):
@@ -156,6 +167,10 @@ class FlatScene:
         d.n_lights = int(self.lights.shape[0])
         if d.n_lights:
             d.lights = ptr(self.lights, RtLight)
+        if self.spheres is not None and len(self.spheres):
+            d.shape_type = ptr(self.shape_type, C.c_uint8)
+            d.n_spheres = int(self.spheres.shape[0])
+            d.spheres = ptr(self.spheres, RtSphere)
         return d, keep
 
     def save_npz(self, path):
@@ -172,7 +187,8 @@ class FlatScene:
                             material_id=self.material_id, light_id=self.light_id,
                             mat_type=self.materials["type"], mat_rgb=self.materials["rgb"], mat_eta=self.materials["eta"],
                             light_prim=self.lights["prim_id"], light_emit=self.lights["emit"],
-                            light_two_sided=self.lights["two_sided"], **extra)
+                            light_two_sided=self.lights["two_sided"],
+                            spheres=(self.spheres if self.spheres is not None else np.zeros(0, _SPHERE_DTYPE)).view(np.uint8), **extra)
 
     @staticmethod
     def load_npz(path):
@@ -189,8 +205,11 @@ class FlatScene:
                                z["raster_to_camera"].astype(np.float32), z["camera_to_world"].astype(np.float32),
                                cf[1], tuple(cf[2:5]), tuple(cf[5:8]), tuple(cf[8:11]), str(z["filename"]))
         tri_n = z["tri_n"] if z["tri_n"].shape[0] else None
+        spheres = None
+        if "spheres" in z.files and z["spheres"].size:
+            spheres = np.ascontiguousarray(z["spheres"]).view(_SPHERE_DTYPE).copy()
         return FlatScene(z["nodes"], z["leaf_idx"], z["bounds"], z["tri_p"], tri_n, z["material_id"], z["light_id"],
-                         mats, lights, cfg)
+                         mats, lights, cfg, None, spheres)
 
 
 def _from_handle(h, with_config):
@@ -228,7 +247,13 @@ def _from_handle(h, with_config):
                            tuple(c.up), c.filename.decode())
     ts = RtHostTreeStats()
     _check(lib.rt_host_tree_stats_get(h, C.byref(ts)))
-    return FlatScene(nodes, leaf_idx, bounds, tri_p, tri_n, material_id, light_id, mats, lights, cfg, ts.as_dict())
+    spheres = None
+    if d.n_spheres:
+        spheres = np.zeros(d.n_spheres, _SPHERE_DTYPE)
+        for i in range(d.n_spheres):
+            sp = d.spheres[i]
+            spheres[i] = (sp.prim_id, sp.radius, tuple(sp.object_to_world), tuple(sp.world_to_object))
+    return FlatScene(nodes, leaf_idx, bounds, tri_p, tri_n, material_id, light_id, mats, lights, cfg, ts.as_dict(), spheres)
 
 
 def load_scene_json(path) -> FlatScene:

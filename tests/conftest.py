@@ -39,6 +39,13 @@ def whitted_scene():
 
 
 @pytest.fixture(scope="session")
+def sphere_scene():
+    """scenes/cornellBox-PathTracing/cornell.json: the cornellBox meshes plus a mirror sphere and an emissive sphere."""
+    from raytracing_amd.scene import FlatScene
+    return FlatScene.load_npz(os.path.join(GOLDEN, "cornell_spheres.npz"))
+
+
+@pytest.fixture(scope="session")
 def reference_png():
     from raytracing_amd.pngio import read_png
     return read_png(os.path.join(GOLDEN, "reference_cornellBox_path_800x800_512spp.png"))[..., :3]

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -78,3 +79,24 @@ def test_product_code_never_touches_the_oracle():
     mk = open(os.path.join(ROOT, "Makefile")).read()
     dev_rule = mk[mk.index("raytracing_amd/lib/libraytracing_amd.so:"):mk.index("oracle/liboracle.so:")]
     assert "oracle" not in dev_rule
+
+
+def test_device_trig_helpers_are_correctly_rounded():
+    """The kernels evaluate cos / sin in double and round once (the reference calls libm's cosf / sinf, whose last
+    bit is implementation-defined). The helpers are host-callable: compare them with numpy's double results rounded
+    to float, over the ranges the path uses (disk mapping: [-pi/4, 3pi/4]; sphere azimuth / polar angle: [0, 2pi])."""
+    import ctypes as C
+    from raytracing_amd.device import device_lib
+    lib = device_lib()
+    rs = np.random.RandomState(5)
+    for name, lo, hi in (("rt_debug_sincos_disk", -np.pi / 4, 3 * np.pi / 4), ("rt_debug_sincos_cr", -2 * np.pi, 2 * np.pi)):
+        fn = getattr(lib, name)
+        fn.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        fn.restype = None
+        th = np.concatenate([rs.uniform(lo, hi, 20000), [v for v in (0.0, lo, hi, np.pi / 2, np.pi, np.pi / 4) if lo <= v <= hi]]).astype(np.float32)
+        s, c = C.c_float(), C.c_float()
+        bad = 0
+        for t in th:
+            fn(float(t), C.byref(s), C.byref(c))
+            bad += (np.float32(np.sin(np.float64(t))) != np.float32(s.value)) + (np.float32(np.cos(np.float64(t))) != np.float32(c.value))
+        assert bad == 0, f"{name}: {bad} results differ from the correctly rounded value"

@@ -141,3 +141,31 @@ def test_render_argument_errors(gpu_ctx, path_scene):
         gpu_ctx.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, spp=4, spp_begin=1)
     with pytest.raises(RtError):
         gpu_ctx.render(spp=0)
+
+
+def test_sphere_scene_path_and_whitted(gpu_ctx, sphere_scene):
+    """cornell.json (mirror sphere + spherical area light): sphere surface reconstruction, cone sampling of the
+    sphere light and ASphereShape::pdf on the device against the oracle. The oracle's sphere code is a restatement
+    read off the reference's source only (the reference ships no output for this scene): parity unpinned beyond that.
+    Path: with the oracle's cos / sin / acos rounded once from double (what the kernels compute) the renders agree
+    bit for bit up to a handful of reordered sums. Whitted with the reference's tile stream: within 1e-4 per pixel."""
+    import oracle_lib
+    gpu_ctx.upload_scene(sphere_scene)
+    cfg = sphere_scene.config.with_resolution(160, 120, spp=16)
+    orc = Oracle(sphere_scene, cfg)
+    gpu_ctx.set_camera(cfg)
+    grgb, gw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3, spp_per_pass=8)
+    oracle_lib.set_trig_mode(True)
+    try:
+        crgb, cw, _ = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3)
+        wrgb_c, ww_c, _ = orc.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=6)
+    finally:
+        oracle_lib.set_trig_mode(False)
+    assert np.array_equal(gw, cw)
+    assert _mean(crgb, cw).mean() > 0.05
+    neq = (grgb != crgb).any(axis=2)
+    assert neq.mean() <= 2e-3, f"{np.count_nonzero(neq)} of {neq.size} pixels differ, max {np.abs(grgb - crgb).max()}"
+    wrgb_g, ww_g = gpu_ctx.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=6)
+    assert np.array_equal(ww_g, ww_c)
+    diff = np.abs(_mean(wrgb_g, ww_g) - _mean(wrgb_c, ww_c))
+    assert diff.max() <= 1e-4, f"max per-pixel difference {diff.max()}"

@@ -124,3 +124,28 @@ def test_traversal_counters_match_oracle(gpu_ctx, path_scene):
     assert st["counted_rays"] == len(o)
     assert st["n_interior"] == cn["n_interior"] and st["n_leaf"] == cn["n_leaf"]
     assert st["n_tri_tests"] == cn["n_tri_tests"] and st["n_leaf_idx"] == cn["n_leaf_idx"]
+
+
+def test_sphere_scene_closest_and_any(gpu_ctx, sphere_scene):
+    """cornell.json: 38 triangles + a mirror sphere + an emissive sphere (ASphereShape::hit, both flavours).
+    Camera rays, rays from everywhere and rays that start ON surfaces (sphere surfaces included: a ray leaving the
+    mirror sphere sees its own sphere at t ~ 0, which only the t0 <= 0 branch of the quadratic keeps out).
+    For a sphere hit the batch interface reports (t, 0, 0) in place of barycentrics."""
+    orc = Oracle(sphere_scene)
+    gpu_ctx.upload_scene(sphere_scene)
+    o, d = raygen.camera_rays(orc, sphere_scene.config, 300_000, seed=11)
+    prim = _compare_closest(gpu_ctx, orc, o, d, label="sphere scene, camera")
+    n_sphere = np.isin(prim, sphere_scene.spheres["prim_id"]).sum()
+    assert n_sphere > 3000, "the camera must see the spheres"
+    o, d = raygen.incoherent_rays(sphere_scene.bounds, 300_000, seed=12)
+    prim = _compare_closest(gpu_ctx, orc, o, d, label="sphere scene, incoherent")
+    assert np.isin(prim, sphere_scene.spheres["prim_id"]).sum() > 3000
+    # second generation: start on whatever was hit (oracle's own hit points), new random directions
+    _, t, _ = orc.trace_closest(o, d)
+    keep = prim >= 0
+    p = (o[keep] + d[keep] * t[keep, None]).astype(np.float32)
+    _, d2 = raygen.incoherent_rays((0, 0, 0, 1, 1, 1), int(keep.sum()), seed=13)
+    _compare_closest(gpu_ctx, orc, p, d2, label="sphere scene, from surfaces")
+    tmax = np.random.RandomState(14).uniform(0, 800, len(p)).astype(np.float32)
+    assert np.array_equal(gpu_ctx.trace_any(p, d2, tmax), orc.trace_any(p, d2, tmax))
+    assert np.array_equal(gpu_ctx.trace_any(o, d), orc.trace_any(o, d))

@@ -136,3 +136,25 @@ def test_fixture_roundtrip(tmp_path, path_scene):
     path_scene.save_npz(p)
     s = FlatScene.load_npz(p)
     assert np.array_equal(s.nodes, path_scene.nodes) and s.config.spp == 512 and s.config.filename == "cornellBox.png"
+
+
+@needs_reference
+def test_loader_handles_sphere_entities(sphere_scene):
+    """cornell.json: "Entity" + "Sphere" shapes (Object/Entity.cpp:11-87, Shape/SphereShape.cpp:12-26): one primitive per
+    sphere in scene order, world bound = objectToWorld(objectBound), lights in hitable order."""
+    s = load_scene_json(os.path.join(REFERENCE, "scenes/cornellBox-PathTracing/cornell.json"))
+    assert s.n_prims == 40 and len(s.lights) == 3 and len(s.spheres) == 2
+    assert list(s.spheres["prim_id"]) == [38, 39] and list(s.spheres["radius"]) == [65.0, 35.0]
+    assert list(s.lights["prim_id"]) == [0, 1, 39]
+    o2w = s.spheres["object_to_world"].reshape(2, 4, 4)
+    assert np.array_equal(o2w[0][3], [200, 232, 150, 1]) and np.array_equal(o2w[1][3], [350, 35, 50, 1])
+    w2o = s.spheres["world_to_object"].reshape(2, 4, 4)
+    assert np.array_equal(w2o[0][3], [-200, -232, -150, 1])
+    assert list(s.shape_type[-2:]) == [1, 1] and s.shape_type[:38].sum() == 0
+    assert s.materials["type"][s.material_id[38]] == 1   # Mirror
+    for name in ("nodes", "leaf_idx", "bounds", "material_id", "light_id"):
+        assert np.array_equal(getattr(s, name), getattr(sphere_scene, name)), name
+    assert np.array_equal(s.spheres, sphere_scene.spheres)
+    # every leaf that references a sphere lies inside the sphere's box, and the sphere is referenced at all
+    refs = set(int(v) for v in s.leaf_idx) | set(int(n[0]) for n in s.nodes if (n[1] & 3) == 3 and (n[1] >> 2) == 1)
+    assert {38, 39} <= refs

@@ -194,3 +194,56 @@ def test_full_render_matches_reference_image(path_scene, reference_png):
     assert psnr > 45.9, psnr
     assert np.abs(d).mean() < 0.72 and np.abs(d).max() <= 32
     assert np.abs(d.mean(axis=(0, 1))).max() < 0.02
+
+
+def test_sphere_hits_are_geometrically_consistent(sphere_scene):
+    """Independent float64 check of the oracle's sphere restatement (no reference output exists for a scene with
+    spheres): a reported sphere hit lies on the sphere at distance t, rays aimed at a sphere's centre from outside hit it
+    at |o - c| - r unless a triangle is nearer, and the batch interface reports (t, 0, 0) instead of barycentrics."""
+    orc = Oracle(sphere_scene)
+    o, d = raygen.incoherent_rays(sphere_scene.bounds, 20000, seed=31)
+    prim, t, bary = orc.trace_closest(o, d)
+    assert (prim >= 38).sum() > 200
+    for sp in sphere_scene.spheres:
+        c = sp["object_to_world"].reshape(4, 4)[3, :3].astype(np.float64)
+        sel = prim == sp["prim_id"]
+        p = o[sel].astype(np.float64) + t[sel, None].astype(np.float64) * d[sel].astype(np.float64)
+        assert np.abs(np.linalg.norm(p - c, axis=1) - sp["radius"]).max() < 2e-3
+        assert np.array_equal(bary[sel][:, 0], t[sel]) and not bary[sel][:, 1:].any()
+        # rays towards the centre
+        oc = (c - o.astype(np.float64))
+        dist = np.linalg.norm(oc, axis=1)
+        outside = dist > sp["radius"] * 1.01
+        dd = (oc / dist[:, None]).astype(np.float32)
+        dd /= np.sqrt((dd.astype(np.float32) ** 2).sum(1, keepdims=True)).astype(np.float32)
+        p2, t2, _ = orc.trace_closest(o[outside], dd[outside])
+        on = p2 == sp["prim_id"]
+        assert on.mean() > 0.3
+        np.testing.assert_allclose(t2[on], (dist[outside] - sp["radius"])[on], rtol=2e-5)
+        assert (t2[~on] < (dist[outside] - sp["radius"])[~on] + 1e-2).all()   # something nearer was hit
+    # any-hit agrees with closest-hit on occlusion
+    occ = orc.trace_any(o, d)
+    assert np.array_equal(occ != 0, prim >= 0)
+
+
+def test_sphere_light_sampling_is_consistent(sphere_scene):
+    """Path and Whitted renders of cornell.json: finite, the emissive sphere is bright, the mirror sphere reflects
+    (a 5x5 block on it is neither black nor as bright as the light), and sample-index shards add up."""
+    cfg = sphere_scene.config.with_resolution(111, 83, spp=8)
+    orc = Oracle(sphere_scene, cfg)
+    rgb, w, st = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=2)
+    assert np.isfinite(rgb).all() and (w >= 8).all()
+    img = rgb / w[..., None]
+    assert img.mean() > 0.05
+    a = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=2, spp_begin=0, spp_end=3)
+    b = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=2, spp_begin=3, spp_end=8)
+    np.testing.assert_allclose(a[0] + b[0], rgb, rtol=1e-5, atol=1e-6)
+    # primary hits decide where the spheres are on the film
+    xy = np.stack(np.meshgrid(np.arange(cfg.width) + 0.5, np.arange(cfg.height) + 0.5), -1).reshape(-1, 2).astype(np.float32)
+    o, d = orc.camera_rays(xy)
+    prim, _, _ = orc.trace_closest(o, d)
+    prim = prim.reshape(cfg.height, cfg.width)
+    light_px, mirror_px = prim == 39, prim == 38
+    assert light_px.sum() > 20 and mirror_px.sum() > 20
+    assert img[light_px].mean() > 1.5          # Le = (2, 2, 2) seen directly
+    assert 0.01 < img[mirror_px].mean() < 1.5

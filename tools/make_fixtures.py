@@ -15,6 +15,7 @@ REF = os.environ.get("RT_REFERENCE", "/root/reference")
 SCENES = {
     "cornellBox_path": "scenes/cornellBox-PathTracing/cornellBox.json",
     "cornellBox_whitted": "scenes/cornellBox-WhittedTracing/cornellBox.json",
+    "cornell_spheres": "scenes/cornellBox-PathTracing/cornell.json",
 }
 
 if __name__ == "__main__":
