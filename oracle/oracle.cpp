@@ -7,6 +7,7 @@
  * 0.9.9.8 semantics; build with -ffp-contract=off):
  *   KD traversal        reference src/core/Accelerators/KDTree.cpp:284-490, Utils/Math.h:572-601
  *   triangle test       src/core/Shape/TriangleShape.cpp:153-453
+ *   sphere              src/core/Shape/SphereShape.cpp:26-235, Utils/Transform.h:75-97, Transform.cpp:97-114
  *   shape sampling      src/core/Shape/Shape.cpp:28-67
  *   BSDF / BxDFs        src/core/Render/BSDF.h:24-72, BSDF.cpp:9-246
  *   materials           src/core/Material/LambertianMaterial.cpp:19-28, MirrorMaterial.cpp:19-29
@@ -20,7 +21,9 @@
  * compiled in this build's environment without its vendored cmake projects (glog, assimp), so the
  * oracle is pinned by the artefacts the reference does hold and publish: the 800x800 512-spp
  * cornellBox.png (tests compare an oracle render against it) and the KD-tree / traversal statistics
- * measured once on the compiled reference. Results that depend on libm's cosf/sinf are "parity unpinned".
+ * measured once on the compiled reference. "Parity unpinned": results that depend on libm's cosf/sinf/acosf, and
+ * the whole sphere part (no output of the reference exists for a scene with spheres; it is checked by float64
+ * geometry tests only).
  */
 #include <algorithm>
 #include <atomic>
