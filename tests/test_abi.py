@@ -45,8 +45,8 @@ def test_struct_layouts_match_the_header():
 #include "raytracing_amd.h"
 #include "rt_host.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(rt_material), sizeof(rt_light), sizeof(rt_scene_desc),
-         sizeof(rt_render_params), sizeof(rt_stats), sizeof(rt_host_config), sizeof(rt_host_tree_stats));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rt_material), sizeof(rt_light), sizeof(rt_scene_desc),
+         sizeof(rt_render_params), sizeof(rt_stats), sizeof(rt_host_config), sizeof(rt_host_tree_stats), sizeof(rt_sphere));
   return 0; }'''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "p.c")
@@ -54,7 +54,7 @@ int main(void) {
         exe = os.path.join(td, "p")
         subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
-    mirrors = [d.RtMaterial, d.RtLight, d.RtSceneDesc, d.RtRenderParams, d.RtStats, d.RtHostConfig, d.RtHostTreeStats]
+    mirrors = [d.RtMaterial, d.RtLight, d.RtSceneDesc, d.RtRenderParams, d.RtStats, d.RtHostConfig, d.RtHostTreeStats, d.RtSphere]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 

@@ -169,3 +169,37 @@ def test_sphere_scene_path_and_whitted(gpu_ctx, sphere_scene):
     assert np.array_equal(ww_g, ww_c)
     diff = np.abs(_mean(wrgb_g, ww_g) - _mean(wrgb_c, ww_c))
     assert diff.max() <= 1e-4, f"max per-pixel difference {diff.max()}"
+
+
+def test_mixed_materials_path_and_whitted(gpu_ctx, path_scene):
+    """cornellBox with the tall box turned into a Mirror and the short box into Glass (eta 1.5): specular reflection,
+    specular transmission with the dielectric Fresnel term, the eta^2 radiance scaling of the path's etaScale, and the
+    Whitted recursion (reflection before transmission, depth 6) against the oracle. Path: bit-equal up to reordered
+    sums with correctly rounded trig; Whitted with the reference's tile stream: within 1e-4 per pixel."""
+    import copy
+    import oracle_lib
+    from raytracing_amd.scene import make_materials
+    s = copy.copy(path_scene)
+    mats = s.materials.copy()
+    mats[6] = make_materials([(2, (0.9, 0.9, 0.9), 1.5)])[0]    # short box: glass
+    mats[7] = make_materials([(1, (0.8, 0.8, 0.8), 1.0)])[0]    # tall box: mirror
+    s.materials = mats
+    cfg = s.config.with_resolution(144, 144, spp=16)
+    orc = Oracle(s, cfg)
+    gpu_ctx.upload_scene(s)
+    gpu_ctx.set_camera(cfg)
+    grgb, gw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=9, spp_per_pass=16)
+    wrgb_g, ww_g = gpu_ctx.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=6, spp=4)
+    oracle_lib.set_trig_mode(True)
+    try:
+        crgb, cw, _ = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=9)
+    finally:
+        oracle_lib.set_trig_mode(False)
+    wrgb_c, ww_c, st = orc.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=6, spp=4)
+    assert np.array_equal(gw, cw) and np.isfinite(grgb).all()
+    neq = (grgb != crgb).any(axis=2)
+    assert neq.mean() <= 2e-3, f"{np.count_nonzero(neq)} of {neq.size} pixels differ, max {np.abs(grgb - crgb).max()}"
+    assert np.array_equal(ww_g, ww_c)
+    assert st["rays_closest"] > 1.5 * 144 * 144 * 4, "the specular recursion must have happened"
+    diff = np.abs(_mean(wrgb_g, ww_g) - _mean(wrgb_c, ww_c))
+    assert diff.max() <= 1e-4, f"max per-pixel difference {diff.max()}"
