@@ -200,6 +200,13 @@ int rt_render(rt_context *ctx, const rt_render_params *params, float *rgb_sum, f
  * queued on the context's stream (rt_synchronize to wait). */
 int rt_render_dev(rt_context *ctx, const rt_render_params *params, float *rgb_sum_dev, float *weight_sum_dev);
 
+/* Film development on the device: what Film::mergeFilmTile + Film::writeImageToFile do to the sums before the PNG is
+ * written (Object/Film.cpp:98-167: RGB -> XYZ -> RGB, divide by weight_sum, clamp at 0, multiply by the film's
+ * "Scale", sRGB curve, 8 bits). rgb8 receives width*height*3 bytes, row-major; the film size is the one given to
+ * rt_set_camera. Encoding the PNG stays with the caller. rt_develop takes host buffers and blocks. */
+int rt_develop(rt_context *ctx, const float *rgb_sum, const float *weight_sum, float film_scale, uint8_t *rgb8);
+int rt_develop_dev(rt_context *ctx, const float *rgb_sum_dev, const float *weight_sum_dev, float film_scale, uint8_t *rgb8_dev);
+
 int rt_synchronize(rt_context *ctx);
 /* The hipStream_t the context launches on (as void*), for callers that record their own events. */
 void *rt_stream(rt_context *ctx);

@@ -693,6 +693,38 @@ __global__ __launch_bounds__(RT_BLOCK) void k_merge_spill(size_t nPix, float *rg
     }
 }
 
+// Film development: the arithmetic of Film::mergeFilmTile + Film::writeImageToFile for splat-free films
+// (Object/Film.cpp:98-167): RGB -> XYZ at merge, XYZ -> RGB, divide by the filter weight sum (clamped at 0), scale,
+// sRGB curve (Utils/Base.h:50-55), quantise to 8 bits. The reference's powf becomes a double pow rounded once.
+__global__ __launch_bounds__(RT_BLOCK) void k_develop(size_t nPix, const float *__restrict__ rgbSum, const float *__restrict__ weightSum,
+                                                      float filmScale, uint8_t *__restrict__ rgb8) {
+    for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < nPix; i += (size_t)gridDim.x * RT_BLOCK) {
+        const float c0 = rgbSum[3 * i], c1 = rgbSum[3 * i + 1], c2 = rgbSum[3 * i + 2];
+        const float x = 0.412453f * c0 + 0.357580f * c1 + 0.180423f * c2;
+        const float y = 0.212671f * c0 + 0.715160f * c1 + 0.072169f * c2;
+        const float z = 0.019334f * c0 + 0.119193f * c1 + 0.950227f * c2;
+        float rgb[3];
+        rgb[0] = 3.240479f * x - 1.537150f * y - 0.498535f * z;
+        rgb[1] = -0.969256f * x + 1.875991f * y + 0.041556f * z;
+        rgb[2] = 0.055648f * x - 0.204043f * y + 1.057311f * z;
+        const float w = weightSum[i];
+        if (w != 0) {
+            const float invWt = 1.0f / w;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rgb[k] = gmax(0.0f, rgb[k] * invWt);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = rgb[k] + 1.0f * 0.0f;
+            v *= filmScale;
+            const float g = (v <= 0.0031308f) ? 12.92f * v : 1.055f * (float)pow((double)v, (double)(float)(1.f / 2.4f)) - 0.055f;
+            float b = 255.f * g + 0.5f;
+            b = b < 0.f ? 0.f : (b > 255.f ? 255.f : b);
+            rgb8[3 * i + k] = (uint8_t)b;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Whitted integrator (Render/Render.cpp:106-152, 473-532)
 // ---------------------------------------------------------------------------------------------------

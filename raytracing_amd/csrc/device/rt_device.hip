@@ -780,6 +780,44 @@ int rt_synchronize(rt_context *c) {
 
 void *rt_stream(rt_context *c) { return c ? (void *)c->stream : nullptr; }
 
+int rt_develop_dev(rt_context *c, const float *rgb, const float *wsum, float film_scale, uint8_t *rgb8) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!rgb || !wsum || !rgb8) return fail(c, RT_ERR_INVALID_ARG, "NULL buffer");
+    if (!c->haveCamera) return fail(c, RT_ERR_NO_CAMERA, "no camera set (the film size comes from rt_set_camera)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->cam.width * c->cam.height;
+    hipLaunchKernelGGL(k_develop, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, n, rgb, wsum, film_scale, rgb8);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_develop(rt_context *c, const float *rgb, const float *wsum, float film_scale, uint8_t *rgb8) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!rgb || !wsum || !rgb8) return fail(c, RT_ERR_INVALID_ARG, "NULL buffer");
+    if (!c->haveCamera) return fail(c, RT_ERR_NO_CAMERA, "no camera set (the film size comes from rt_set_camera)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->cam.width * c->cam.height;
+    float *dR = nullptr, *dW = nullptr;
+    uint8_t *d8 = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() { if (dR) (void)hipFree(dR); if (dW) (void)hipFree(dW); if (d8) (void)hipFree(d8); };
+#define DEV_TRY(expr)                                                                       \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(c, RT_ERR_HIP, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    DEV_TRY(hipMalloc((void **)&dR, n * 3 * sizeof(float)));
+    DEV_TRY(hipMalloc((void **)&dW, n * sizeof(float)));
+    DEV_TRY(hipMalloc((void **)&d8, n * 3));
+    DEV_TRY(hipMemcpy(dR, rgb, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    DEV_TRY(hipMemcpy(dW, wsum, n * sizeof(float), hipMemcpyHostToDevice));
+    rc = rt_develop_dev(c, dR, dW, film_scale, d8);
+    if (rc == RT_OK) {
+        DEV_TRY(hipStreamSynchronize(c->stream));
+        DEV_TRY(hipMemcpy(rgb8, d8, n * 3, hipMemcpyDeviceToHost));
+    }
+#undef DEV_TRY
+    cleanup();
+    return rc;
+}
+
 int rt_set_option(rt_context *c, int option, int value) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (option == RT_OPTION_TRACE_SCHEDULE) {

@@ -15,7 +15,7 @@ _dev = None
 EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_version", "rt_upload_scene", "rt_set_camera", "rt_trace_closest",
     "rt_trace_any", "rt_trace_closest_dev", "rt_trace_any_dev", "rt_render", "rt_render_dev", "rt_synchronize", "rt_stream",
-    "rt_get_stats", "rt_reset_stats", "rt_set_option",
+    "rt_get_stats", "rt_reset_stats", "rt_set_option", "rt_develop", "rt_develop_dev",
 ]
 
 
@@ -49,6 +49,8 @@ def device_lib():
         lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
         lib.rt_reset_stats.argtypes = [vp]
         lib.rt_set_option.argtypes = [vp, i32, i32]
+        lib.rt_develop.argtypes = [vp, vp, vp, C.c_float, vp]
+        lib.rt_develop_dev.argtypes = [vp, vp, vp, C.c_float, vp]
         _dev = lib
     return _dev
 
@@ -174,6 +176,17 @@ class Context:
         """Ray-to-lane schedule: "auto" (default), "lockstep" (one ray per lane) or "stream" (lanes take new rays as they finish)."""
         value = {"auto": 0, "lockstep": 1, "stream": 2}[schedule]
         self._check(self._lib.rt_set_option(self._h, 1, value))
+
+    def develop(self, rgb_sum, weight_sum, film_scale=1.0):
+        """Film sums (host arrays of the camera's size) -> (H, W, 3) uint8 sRGB image, computed on the device."""
+        rgb_sum = np.ascontiguousarray(rgb_sum, np.float32)
+        weight_sum = np.ascontiguousarray(weight_sum, np.float32)
+        out = np.empty(rgb_sum.shape, np.uint8)
+        self._check(self._lib.rt_develop(self._h, rgb_sum.ctypes.data, weight_sum.ctypes.data, float(film_scale), out.ctypes.data))
+        return out
+
+    def develop_dev(self, rgb_ptr, weight_ptr, out_ptr, film_scale=1.0):
+        self._check(self._lib.rt_develop_dev(self._h, rgb_ptr, weight_ptr, float(film_scale), out_ptr))
 
     def synchronize(self):
         self._check(self._lib.rt_synchronize(self._h))

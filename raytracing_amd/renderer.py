@@ -20,10 +20,14 @@ from .scene import FlatScene, develop, load_scene_json
 class Film:
     """rgb_sum / weight_sum as FilmTile::addSample accumulates them (reference src/core/Object/Film.h:111-155)."""
 
-    def __init__(self, rgb_sum, weight_sum, scale=1.0, filename="rendered.png"):
+    def __init__(self, rgb_sum, weight_sum, scale=1.0, filename="rendered.png", context=None):
         self.rgb_sum, self.weight_sum, self.scale, self.filename = rgb_sum, weight_sum, scale, filename
+        self._ctx = context
 
     def to_rgb8(self):
+        """8-bit sRGB image: on the device when the film came from a renderer, else through the host restatement."""
+        if self._ctx is not None:
+            return self._ctx.develop(self.rgb_sum, self.weight_sum, self.scale)
         return develop(self.rgb_sum, self.weight_sum, self.scale)
 
     def write_image_to_file(self, path=None):   # Film::writeImageToFile (reference src/core/Object/Film.cpp:116-167)
@@ -57,7 +61,7 @@ class SamplerRenderer:
         rgb, w = self.ctx.render(integrator=self.integrator, spp=self.spp if self.spp is not None else cfg.spp,
                                  max_depth=self.max_depth if self.max_depth is not None else cfg.max_depth,
                                  rng_mode=self.rng_mode, seed=self.seed, spp_begin=spp_begin, spp_end=spp_end)
-        film = Film(rgb, w, cfg.film_scale, cfg.filename)
+        film = Film(rgb, w, cfg.film_scale, cfg.filename, self.ctx)
         if write:
             film.write_image_to_file()
         return film

@@ -203,3 +203,24 @@ def test_mixed_materials_path_and_whitted(gpu_ctx, path_scene):
     assert st["rays_closest"] > 1.5 * 144 * 144 * 4, "the specular recursion must have happened"
     diff = np.abs(_mean(wrgb_g, ww_g) - _mean(wrgb_c, ww_c))
     assert diff.max() <= 1e-4, f"max per-pixel difference {diff.max()}"
+
+
+def test_film_development_on_the_device(gpu_ctx, path_scene):
+    """rt_develop against the host restatement of Film::writeImageToFile's arithmetic (rt_host_develop, itself pinned
+    to hand-computed values in the CPU suite). The only libm call is the sRGB curve's powf: the device evaluates pow in
+    double and rounds once, so a byte may differ by one where 255*g + 0.5 sits on an integer (bar: < 1e-4 of the
+    bytes, none by more than 1)."""
+    cfg = path_scene.config.with_resolution(200, 150, spp=4)
+    gpu_ctx.upload_scene(path_scene)
+    gpu_ctx.set_camera(cfg)
+    rgb, w = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=2)
+    rs = np.random.RandomState(3)
+    cases = [(rgb, w, 1.0), (rgb, w, 2.5),
+             ((rs.uniform(-0.2, 3.0, rgb.shape) * 7).astype(np.float32), np.full(w.shape, 7, np.float32), 1.0),
+             (rgb, np.zeros_like(w), 1.0)]
+    for r_, w_, scale in cases:
+        host = develop(r_, w_, scale)
+        dev = gpu_ctx.develop(r_, w_, scale)
+        d = np.abs(host.astype(np.int16) - dev.astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-4, f"{np.count_nonzero(d)} bytes differ, max {d.max()}"
+    assert gpu_ctx.develop(rgb, w).mean() > 20
