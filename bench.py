@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 WIDTH, HEIGHT = 1920, 1080
-SPP_PER_STEP = 8
+SPP_PER_STEP = int(os.environ.get("RT_BENCH_SPP_PER_STEP", "32"))
 MAX_DEPTH = 15
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 FP32_VALU_PEAK_TFLOPS = 157.3
@@ -72,7 +72,7 @@ def cpu_baseline(scene, cfg, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

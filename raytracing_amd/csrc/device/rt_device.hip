@@ -303,7 +303,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     const uint64_t nPix = (uint64_t)sbW * sbH;
     if (nPix == 0 || p->spp_end == p->spp_begin) return RT_OK;
     int sppPass = p->spp_per_pass;
-    if (sppPass <= 0) sppPass = (int)std::max<uint64_t>(1, (1ull << 24) / nPix);
+    if (sppPass <= 0) sppPass = (int)std::max<uint64_t>(1, (1ull << 26) / nPix);   // 67 M paths in flight: 18 GB of queues per pipeline
     sppPass = std::min(sppPass, p->spp_end - p->spp_begin);
     if (nPix * (uint64_t)sppPass >= (1ull << 30)) sppPass = (int)std::max<uint64_t>(1, ((1ull << 30) - 1) / nPix);
     if (nPix >= (1ull << 30)) return fail(c, RT_ERR_UNSUPPORTED, "film too large");

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 timeout -k 10 200 python -u $R/__graft_entry__.py smoke > $R/gpurun_out/${TAG}_smoke.log 2>&1 || { echo SMOKE FAILED; tail -5 $R/gpurun_out/${TAG}_smoke.log; exit 1; }
 tail -1 $R/gpurun_out/${TAG}_smoke.log
-timeout -k 10 300 python -u $R/bench.py --steps 64 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err || { echo BENCH FAILED; tail -5 $R/gpurun_out/${TAG}_bench.err; exit 1; }
+timeout -k 10 300 python -u $R/bench.py --steps 32 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err || { echo BENCH FAILED; tail -5 $R/gpurun_out/${TAG}_bench.err; exit 1; }
 python3 -c "
 import json,sys
 d=json.load(open('$R/gpurun_out/${TAG}_bench.json'))

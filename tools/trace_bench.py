@@ -79,6 +79,18 @@ def main():
     keep = prim >= 0
     p = torch.where(keep.unsqueeze(1), p, torch.tensor(eye, device=dev).expand(n, 3))
     run("bounce", p, drand)
+    # the same rays grouped by direction octant (stable: pixel order kept inside a group)
+    octant = (drand[:, 0] > 0).int() + 2 * (drand[:, 1] > 0).int() + 4 * (drand[:, 2] > 0).int()
+    order = torch.sort(octant, stable=True).indices
+    run("bounce/oct", p[order], drand[order])
+    # cosine-weighted directions about +y from floor-like points would be the path tracer's; here: hemisphere facing the box centre
+    centre = torch.tensor([278.0, 274.4, 279.6], device=dev)
+    flip = ((centre - p) * drand).sum(1) < 0
+    dhemi = torch.where(flip.unsqueeze(1), -drand, drand)
+    run("inward", p, dhemi)
+    octant = (dhemi[:, 0] > 0).int() + 2 * (dhemi[:, 1] > 0).int() + 4 * (dhemi[:, 2] > 0).int()
+    order = torch.sort(octant, stable=True).indices
+    run("inward/oct", p[order], dhemi[order])
 
     o, d = raygen.incoherent_rays(scene.bounds, n, 3)
     run("uniform", torch.tensor(o, device=dev), torch.tensor(d, device=dev))
