@@ -168,7 +168,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any_stream(DevScene sc, uint
 // wavefront path tracer
 // ---------------------------------------------------------------------------------------------------
 // Queue slot layouts (all float4, indexed by queue slot so a wave reads contiguous memory):
-//   ray   A = {o.xyz, d.x}   B = {d.y, d.z, bits(pathId | specularBounce << 31), -}
+//   ray   A = {o.xyz, -}   B = {d.xyz, bits(pathId | specularBounce << 31)}   (shading a triangle hit needs B only)
 //   hit     = {bits(prim), b0, b1, b2}
 //   shadow A = {o.xyz, d.x}  B = {d.y, d.z, bits(pathId), c.r}  C = {c.g, c.b, -, -}
 //   probe   = 6 float4: {p, hasShadow} {shadowDir, pathId} {A, light} {wi, weight} {f|cos|, pdf} {beta, selPdf}
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(CameraDev cam, PassInfo ps,
         const float u0 = pcg_float(rng), u1 = pcg_float(rng);
         f3 o, d;
         camera_ray(cam, (float)px + u0, (float)py + u1, o, d);
-        pb.rayA[0][id] = make_float4(o.x, o.y, o.z, d.x);
-        pb.rayB[0][id] = make_float4(d.y, d.z, __uint_as_float(id), 0.f);
+        pb.rayA[0][id] = make_float4(o.x, o.y, o.z, 0.f);
+        pb.rayB[0][id] = make_float4(d.x, d.y, d.z, __uint_as_float(id));
         pb.L[id] = make_float4(0.f, 0.f, 0.f, 1.f);
         pb.beta[id] = make_float4(1.f, 1.f, 1.f, 0.f);
         pb.rng[id] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const float4 a = rayA[i], b = rayB[i];
         RayCtx r;
-        ray_setup(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+        ray_setup(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z));
         HitRec h;
         kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
         hit[i] = make_float4(__int_as_float(h.prim), h.b0, h.b1, h.b2);
@@ -298,7 +298,7 @@ struct ExtendJob {
     RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
         const float4 a = rayA[j], b = rayB[j];
         ro = mk3(a.x, a.y, a.z);
-        rd = mk3(a.w, b.x, b.y);
+        rd = mk3(b.x, b.y, b.z);
         tm = RT_INF;
         return true;
     }
@@ -347,19 +347,20 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
 #pragma unroll
         for (int k = 0; k < 6; ++k) pr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (alive) {
-            const float4 ra = pb.rayA[cur][i], rb = pb.rayB[cur][i];
+            const float4 rb = pb.rayB[cur][i];
+            const float4 ra = SPH ? pb.rayA[cur][i] : make_float4(0.f, 0.f, 0.f, 0.f);   // only a sphere hit needs the origin
             const float4 hr = pb.hit[i];
-            const uint32_t idBits = __float_as_uint(rb.z);
+            const uint32_t idBits = __float_as_uint(rb.w);
             const uint32_t pathId = idBits & 0x7fffffffu;
             const bool specularBounce = (idBits >> 31) != 0;
-            const f3 rd = mk3(ra.w, rb.x, rb.y);
+            const f3 rd = mk3(rb.x, rb.y, rb.z);
             const int prim = __float_as_int(hr.x);
             alive = false;   // set again when the path continues
             if (prim >= 0) {
                 Surf sf;
                 surface_at<SPH>(sc, prim, hr.y, hr.z, hr.w, mk3(ra.x, ra.y, ra.z), rd, sf);
                 float4 L4 = pb.L[pathId];
-                float4 beta4 = pb.beta[pathId];
+                const float4 beta4 = pb.beta[pathId];
                 f3 beta = mk3(beta4.x, beta4.y, beta4.z);
                 float etaScale = L4.w;
                 bool Ldirty = false;
@@ -467,8 +468,8 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
                                 else beta = beta / (1 - q);
                             }
                             if (alive) {
-                                nA = make_float4(sf.p.x, sf.p.y, sf.p.z, nd.x);
-                                nB = make_float4(nd.y, nd.z, __uint_as_float(pathId | (spec ? 0x80000000u : 0u)), 0.f);
+                                nA = make_float4(sf.p.x, sf.p.y, sf.p.z, 0.f);
+                                nB = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pathId | (spec ? 0x80000000u : 0u)));
                                 pb.beta[pathId] = make_float4(beta.x, beta.y, beta.z, 0.f);
                                 pb.rng[pathId] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), st.z, st.w);
                                 if (etaScale != L4.w) { L4.w = etaScale; Ldirty = true; }

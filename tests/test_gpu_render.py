@@ -224,3 +224,33 @@ def test_film_development_on_the_device(gpu_ctx, path_scene):
         d = np.abs(host.astype(np.int16) - dev.astype(np.int16))
         assert d.max() <= 1 and (d != 0).mean() < 1e-4, f"{np.count_nonzero(d)} bytes differ, max {d.max()}"
     assert gpu_ctx.develop(rgb, w).mean() > 20
+
+
+def test_full_size_frame_properties(gpu_ctx, path_scene):
+    """The benchmark configuration's frame (1920x1080), where the oracle is too slow to be the checker: size-independent
+    properties instead. (a) every pixel receives exactly spp samples (plus border-rounded neighbours); (b) two
+    sample-index shards add up to the unsharded frame bit for bit (up to reordered border sums); (c) the pass size does
+    not change the result; (d) the frame's mean radiance agrees with a 240x135 render of the same camera, which the
+    small-size tests tie to the oracle (Monte Carlo: within 1 %); (e) rays per sample match the measured 3.7."""
+    cfg = path_scene.config.with_resolution(1920, 1080, spp=8)
+    gpu_ctx.upload_scene(path_scene)
+    gpu_ctx.set_camera(cfg)
+    gpu_ctx.reset_stats()
+    full, fw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, seed=4, spp_per_pass=8)
+    st = gpu_ctx.stats()
+    assert fw.min() >= 8 and (fw != 8).mean() < 2e-3 and np.isfinite(full).all()
+    assert st["camera_samples"] == 1920 * 1080 * 8
+    assert 3.5 < (st["rays_closest"] + st["rays_any"]) / st["camera_samples"] < 3.9
+    rgb = np.zeros_like(full)
+    w = np.zeros_like(fw)
+    gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, seed=4, spp_begin=0, spp_end=3, spp_per_pass=2, rgb_sum=rgb, weight_sum=w)
+    gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, seed=4, spp_begin=3, spp_end=8, spp_per_pass=5, rgb_sum=rgb, weight_sum=w)
+    assert np.array_equal(w, fw)
+    neq = (rgb != full).any(axis=2)
+    assert neq.mean() < 2e-3 and np.abs(rgb - full).max() <= 2e-6 * np.abs(full).max()
+    small = path_scene.config.with_resolution(240, 135, spp=512)
+    gpu_ctx.set_camera(small)
+    srgb, sw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, seed=5)
+    big_mean = (full / fw[..., None]).mean((0, 1))
+    small_mean = (srgb / sw[..., None]).mean((0, 1))
+    assert np.abs(big_mean - small_mean).max() <= 0.01 * small_mean.max(), (big_mean, small_mean)
