@@ -13,6 +13,10 @@
 #include "../../../include/raytracing_amd.h"
 #include "kernels.h"
 
+#ifndef RT_PIPES
+#define RT_PIPES 2   // wavefront pipelines (streams + buffer sets) that overlap consecutive passes
+#endif
+
 namespace {
 
 std::string g_create_err;
@@ -54,7 +58,7 @@ struct rt_context {
 
     // path tracer pipelines: consecutive passes alternate between two sets of buffers on two streams, so the
     // small late-bounce launches of one pass overlap the large early-bounce launches of the next
-    static constexpr int kPipes = 2;
+    static constexpr int kPipes = RT_PIPES;
     PathBuffers pb[kPipes]{};
     hipStream_t pipeStream[kPipes] = {};
     hipEvent_t pipeFilmDone[kPipes] = {};
