@@ -254,3 +254,51 @@ def test_full_size_frame_properties(gpu_ctx, path_scene):
     big_mean = (full / fw[..., None]).mean((0, 1))
     small_mean = (srgb / sw[..., None]).mean((0, 1))
     assert np.abs(big_mean - small_mean).max() <= 0.01 * small_mean.max(), (big_mean, small_mean)
+
+
+def test_scene_in_hbm_with_mixed_materials(gpu_ctx, path_scene):
+    """A 30k-triangle soup under the cornellBox luminaire, materials by index stripe (60 % Lambertian, 25 % Mirror,
+    15 % Glass) - a small version of the mixed-BSDF mesh configuration. The traversal tables do not fit in LDS, so this
+    is the path through the global-memory kernels, with the extend and shadow stages under both ray-to-lane schedules
+    (lockstep and streaming must give the same image; the oracle decides which image)."""
+    import oracle_lib
+    import raygen
+    from raytracing_amd.scene import build_scene, make_lights, make_materials
+    n = 30_000
+    tri = raygen.triangle_soup(n, seed=21, lo=100.0, hi=450.0, emin=8.0, emax=30.0)
+    lum = np.array([[343, 548.7, 227, 343, 548.7, 332, 213, 548.7, 332], [343, 548.7, 227, 213, 548.7, 332, 213, 548.7, 227]], np.float32)
+    tri = np.concatenate([tri, lum])
+    stripe = np.arange(n) % 20
+    mat = np.where(stripe < 12, 0, np.where(stripe < 17, 1, 2)).astype(np.int32)
+    mat = np.concatenate([mat, [0, 0]]).astype(np.int32)
+    light_id = np.full(n + 2, -1, np.int32)
+    light_id[n:] = [0, 1]
+    cfg = path_scene.config.with_resolution(96, 72, spp=8)
+    scene = build_scene(tri, mat, make_materials([(0, (0.73, 0.6, 0.5), 1.0), (1, (0.9, 0.9, 0.9), 1.0), (2, (0.95, 0.95, 0.95), 1.5)]),
+                        light_id=light_id, lights=make_lights([(n, (17, 12, 4), 0), (n + 1, (17, 12, 4), 0)]), config=cfg)
+    assert scene.n_nodes * 8 + len(scene.leaf_idx) * 4 + scene.n_prims * 144 > 40 * 1024
+    orc = Oracle(scene, cfg)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cfg)
+    oracle_lib.set_trig_mode(True)
+    try:
+        crgb, cw, st = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=6, max_depth=8)
+    finally:
+        oracle_lib.set_trig_mode(False)
+    wrgb_c, ww_c, _ = orc.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=5, spp=2)
+    assert _mean(crgb, cw).mean() > 0.01 and st["rays_closest"] > 1.5 * 96 * 72 * 8
+    images = {}
+    try:
+        for schedule in ("lockstep", "stream"):
+            gpu_ctx.set_trace_schedule(schedule)
+            grgb, gw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=6, max_depth=8, spp_per_pass=3)
+            assert np.array_equal(gw, cw)
+            neq = (grgb != crgb).any(axis=2)
+            assert neq.mean() <= 2e-3, f"{schedule}: {np.count_nonzero(neq)} of {neq.size} pixels differ, max {np.abs(grgb - crgb).max()}"
+            images[schedule] = grgb
+    finally:
+        gpu_ctx.set_trace_schedule("auto")
+    assert np.array_equal(images["lockstep"], images["stream"])
+    wrgb_g, ww_g = gpu_ctx.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=5, spp=2)
+    assert np.array_equal(ww_g, ww_c)
+    assert np.abs(_mean(wrgb_g, ww_g) - _mean(wrgb_c, ww_c)).max() <= 1e-4

@@ -106,7 +106,7 @@ def test_soup_scene_global_memory_path(gpu_ctx):
     gpu_ctx.upload_scene(scene)
     o, d = raygen.incoherent_rays(scene.bounds, 200_000, seed=12)
     cp, ct, cb, cn = orc.trace_closest(o, d, counters=True)
-    assert cn["max_stack"] > 8, "the batch must exercise the stack's overflow part"
+    assert cn["max_stack"] > 12, "the batch must exercise the stack's overflow part (12 entries live in LDS)"
     _compare_closest(gpu_ctx, orc, o, d, label="soup")
     tmax = np.full(len(o), 30.0, np.float32)
     assert np.array_equal(gpu_ctx.trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
