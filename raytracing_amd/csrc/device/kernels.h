@@ -212,32 +212,29 @@ RT_DEV uint64_t path_sequence(const CameraDev &cam, const PassInfo &ps, uint32_t
     return counter_sequence(pix, ps.sppTotal, ps.sppBase + sLocal, ps.seed);
 }
 
-// Block-aggregated append to three queues at once: wave ballots give per-wave counts, one lane per queue
-// issues a single atomicAdd for the whole 256-thread block, and every lane gets base + rank. All threads of the
-// block must call it (it synchronises). `lds` holds 16 dwords.
-RT_DEV void block_append3(uint32_t *lds, uint32_t *c0, uint32_t *c1, uint32_t *c2, bool w0, bool w1, bool w2, uint32_t &s0, uint32_t &s1,
-                          uint32_t &s2) {
+// Block-aggregated append to two queues at once: wave ballots give per-wave counts, one lane per queue issues a
+// single atomicAdd for the whole 256-thread block, and every lane gets base + rank. All threads of the block must
+// call it (it synchronises). `lds` holds 16 dwords.
+RT_DEV void block_append2(uint32_t *lds, uint32_t *c0, uint32_t *c1, bool w0, bool w1, uint32_t &s0, uint32_t &s1) {
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1), m2 = __ballot(w2);
+    const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1);
     const unsigned long long below = (1ull << lane) - 1ull;
     if (lane == 0) {
         lds[0 * 4 + wave] = (uint32_t)__popcll(m0);
         lds[1 * 4 + wave] = (uint32_t)__popcll(m1);
-        lds[2 * 4 + wave] = (uint32_t)__popcll(m2);
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 2) {
         const uint32_t q = threadIdx.x;
         const uint32_t total = lds[q * 4 + 0] + lds[q * 4 + 1] + lds[q * 4 + 2] + lds[q * 4 + 3];
-        uint32_t *ctr = q == 0 ? c0 : (q == 1 ? c1 : c2);
+        uint32_t *ctr = q == 0 ? c0 : c1;
         lds[12 + q] = total ? atomicAdd(ctr, total) : 0u;
     }
     __syncthreads();
-    uint32_t pre0 = 0, pre1 = 0, pre2 = 0;
-    for (uint32_t w = 0; w < wave; ++w) { pre0 += lds[0 * 4 + w]; pre1 += lds[1 * 4 + w]; pre2 += lds[2 * 4 + w]; }
+    uint32_t pre0 = 0, pre1 = 0;
+    for (uint32_t w = 0; w < wave; ++w) { pre0 += lds[0 * 4 + w]; pre1 += lds[1 * 4 + w]; }
     s0 = lds[12] + pre0 + (uint32_t)__popcll(m0 & below);
     s1 = lds[13] + pre1 + (uint32_t)__popcll(m1 & below);
-    s2 = lds[14] + pre2 + (uint32_t)__popcll(m2 & below);
     __syncthreads();   // lds is reused by the next iteration
 }
 
@@ -328,8 +325,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_stream(DevScene sc, const f
 // One bounce of PathRenderer::Li (Render/Render.cpp:363-445) for every live path, after its closest hit
 // is known: emission, light sampling with MIS (uniformSampleOneLight / estimateDirect, :189-312), BSDF
 // sampling, Russian roulette. Visibility is resolved by k_shadow / k_probe afterwards.
+#ifndef RT_SHADE_MIN_BLOCKS
+#define RT_SHADE_MIN_BLOCKS 2   // workgroups per CU the register allocation of k_shade is held to
+#endif
 template <int MATSET, bool SPH>
-__global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev cam, PassInfo ps, PathBuffers pb, int bounce) {
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScene sc, CameraDev cam, PassInfo ps, PathBuffers pb, int bounce) {
     const int cur = bounce & 1, nxt = cur ^ 1;
     __shared__ uint32_t s_app[16];
     const uint32_t n = pb.counts[cnt_index(bounce, 0)];
@@ -339,13 +339,10 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
     const uint32_t nRound = (n + RT_BLOCK - 1u) & ~(RT_BLOCK - 1u);   // whole blocks enter the loop: the append synchronises
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < nRound; i += gridDim.x * RT_BLOCK) {
         bool alive = i < n;
-        bool wantShadow = false, wantProbe = false;
+        bool wantShadow = false;
         float4 sA, sB, sC;          // shadow entry
-        float4 pr[6];               // probe entry
         float4 nA, nB;              // next ray
         sA = sB = sC = nA = nB = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) pr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (alive) {
             const float4 rb = pb.rayB[cur][i];
             const float4 ra = SPH ? pb.rayA[cur][i] : make_float4(0.f, 0.f, 0.f, 0.f);   // only a sphere hit needs the origin
@@ -425,7 +422,9 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
                                 }
                             }
                             if (needProbe) {
-                                wantProbe = true;
+                                // rare (the BSDF sample has to point at the chosen light): appended right here with one
+                                // atomic per lane instead of being carried in 24 registers to the block-wide append
+                                float4 *pr = pb.probe + (size_t)atomicAdd(cntProbe, 1u) * 6;
                                 pr[0] = make_float4(sf.p.x, sf.p.y, sf.p.z, haveShadow ? 1.f : 0.f);
                                 pr[1] = make_float4(shD.x, shD.y, shD.z, __uint_as_float(pathId));
                                 pr[2] = make_float4(A.x, A.y, A.z, __int_as_float(li));
@@ -480,14 +479,10 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(DevScene sc, CameraDev ca
                 if (Ldirty) pb.L[pathId] = L4;
             }
         }
-        uint32_t slotN, slotS, slotP;
-        block_append3(s_app, cntNext, cntShadow, cntProbe, alive, wantShadow, wantProbe, slotN, slotS, slotP);
+        uint32_t slotN, slotS;
+        block_append2(s_app, cntNext, cntShadow, alive, wantShadow, slotN, slotS);
         if (alive) { pb.rayA[nxt][slotN] = nA; pb.rayB[nxt][slotN] = nB; }
         if (wantShadow) { pb.shA[slotS] = sA; pb.shB[slotS] = sB; pb.shC[slotS] = sC; }
-        if (wantProbe) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) pb.probe[(size_t)slotP * 6 + k] = pr[k];
-        }
     }
 }
 
