@@ -312,7 +312,13 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     if (nPix * (uint64_t)sppPass >= (1ull << 30)) sppPass = (int)std::max<uint64_t>(1, ((1ull << 30) - 1) / nPix);
     if (nPix >= (1ull << 30)) return fail(c, RT_ERR_UNSUPPORTED, "film too large");
     int rc;
-    if ((rc = ensure_path_buffers(c, nPix * (uint64_t)sppPass, p->max_depth))) return rc;
+    // the queues are sized for a 288 GB part; on a device with less free memory fall back to fewer samples in flight
+    while ((rc = ensure_path_buffers(c, nPix * (uint64_t)sppPass, p->max_depth)) != RT_OK) {
+        free_path_buffers(c);
+        (void)hipGetLastError();
+        if (sppPass == 1 || p->spp_per_pass > 0) return rc;   // an explicit request is not second-guessed
+        sppPass = (sppPass + 1) / 2;
+    }
     if ((rc = ensure_spill(c))) return rc;
     const bool stats = p->collect_stats != 0;
     const size_t lds = trace_lds_bytes(c), ldsStream = stream_lds_bytes_of(c);
