@@ -59,6 +59,20 @@ RT_DEV void pcg_set_sequence(Pcg &r, uint64_t seq) {
     r.state += 0x853c49e6748fea9bULL;
     pcg_next(r);
 }
+// Rng::advance (reference src/core/Utils/Math.h:730-746): jumps the stream forward by `delta` draws in O(log delta).
+RT_DEV void pcg_advance(Pcg &r, uint64_t delta) {
+    uint64_t curMult = 0x5851f42d4c957f2dULL, curPlus = r.inc, accMult = 1u, accPlus = 0u;
+    while (delta > 0) {
+        if (delta & 1) {
+            accMult *= curMult;
+            accPlus = accPlus * curMult + curPlus;
+        }
+        curPlus = (curMult + 1) * curPlus;
+        curMult *= curMult;
+        delta /= 2;
+    }
+    r.state = accMult * r.state + accPlus;
+}
 RT_DEV float pcg_float(Pcg &r) { return gmin(RT_ONE_MINUS_EPS, (float)pcg_next(r) * 2.3283064365386963e-10f); }
 RT_DEV uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ULL;

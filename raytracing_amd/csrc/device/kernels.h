@@ -742,7 +742,7 @@ struct WFrame {
 // evaluation would consume (the specular tree does not depend on them).
 template <bool LDS_SCENE, bool STATS, bool SPH>
 RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f3 ro, f3 rdir, Pcg &rng, int maxDepth, bool countOnly,
-                     TravCounters &cn, uint32_t &nClosest, uint32_t &nAny) {
+                     TravCounters &cn, uint32_t &nClosest, uint32_t &nAny, uint32_t &nDraws) {
     WFrame fr[RT_WHITTED_MAX_FRAMES];
     int sp = 0;
     f3 Lret = mk3(0.f, 0.f, 0.f);
@@ -767,6 +767,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
                 if (!countOnly && sf.light >= 0) L = L + light_L(sc.lights[sf.light], sf.n, wo);
                 for (uint32_t li = 0; li < sc.nLights; ++li) {
                     const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+                    nDraws += 2;
                     if (countOnly) continue;
                     f3 wi, pShape;
                     float pdf;
@@ -815,6 +816,7 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
             float pdf = 0;
             int sampledType = 0;
             const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+            nDraws += 2;
             const f3 fv = bsdf_sample(bs, wo, wi, u0, u1, pdf, sampledType, type);
             if (pdf > 0.f && !black3(fv) && absdot3(wi, sf.n) != 0.f) {
                 f.f = fv;
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted_prepass(DevScene sc, Camer
     Pcg rng;
     pcg_set_sequence(rng, (uint64_t)t);
     TravCounters cn = {0, 0, 0, 0};
-    uint32_t nc = 0, na = 0;
+    uint32_t nc = 0, na = 0, nd = 0;
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
             pixelState[(size_t)(y - cam.sb[1]) * sbW + (x - cam.sb[0])] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
@@ -860,13 +862,86 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted_prepass(DevScene sc, Camer
                 const float u0 = pcg_float(rng), u1 = pcg_float(rng);
                 f3 o, d;
                 camera_ray(cam, (float)x + u0, (float)y + u1, o, d);
-                whitted_li<LDS_SCENE, false, SPH>(sc, tb, stk, o, d, rng, maxDepth, true, cn, nc, na);
+                whitted_li<LDS_SCENE, false, SPH>(sc, tb, stk, o, d, rng, maxDepth, true, cn, nc, na, nd);
             }
         }
 }
 
 // Step 2 (and the whole job in counter mode): one lane per pixel evaluates its samples in order and adds
 // them to the film.
+// Reference tile stream, parallel form of step 1. A pixel's samples start `offset` draws into its tile's stream,
+// where offset = draws of all earlier pixels of the tile - which depend on where THEIR samples fall, i.e. on their own
+// offsets. Fixed point: every pixel counts the draws of its samples from a guessed offset (one lane per pixel, all
+// tiles at once), a scan turns the counts into new offsets, and the two steps repeat until no offset changes. The
+// count of a pixel rarely depends on the jitter (all its samples hit or all miss), so a good first guess converges
+// at once; after pass i the first i pixels of every tile are final, so 256 passes always suffice, and a tile whose
+// offsets a scan left unchanged is final and is skipped from then on (tileLive). The serial kernel above remains the
+// fallback. Slot = tile * 256 + row-major position in the 16x16 tile.
+template <bool LDS_SCENE, bool SPH>
+__global__ __launch_bounds__(RT_BLOCK) void k_whitted_count(DevScene sc, CameraDev cam, int spp, int maxDepth, uint32_t nTiles, uint32_t ntx,
+                                                            const unsigned long long *__restrict__ offsets, const uint32_t *__restrict__ tileLive,
+                                                            unsigned long long *__restrict__ draws, uint2 *pixelState) {
+    extern __shared__ uint4 smem[];
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    const int sbW = cam.sb[2] - cam.sb[0], sbH = cam.sb[3] - cam.sb[1];
+    const uint32_t nSlots = nTiles * 256u;
+    TravCounters cn = {0, 0, 0, 0, 0};
+    uint32_t nc = 0, na = 0;
+    for (uint32_t pi = blockIdx.x * RT_BLOCK + threadIdx.x; pi < nSlots; pi += gridDim.x * RT_BLOCK) {
+        const uint32_t tile = pi / 256, inTile = pi % 256;
+        if (!tileLive[tile]) continue;
+        const int lx = (int)(tile % ntx) * 16 + (int)(inTile % 16), ly = (int)(tile / ntx) * 16 + (int)(inTile / 16);
+        if (lx >= sbW || ly >= sbH) { draws[pi] = 0; continue; }
+        Pcg rng;
+        pcg_set_sequence(rng, (uint64_t)tile);
+        pcg_advance(rng, offsets[pi]);
+        pixelState[(size_t)ly * sbW + lx] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+        const int x = cam.sb[0] + lx, y = cam.sb[1] + ly;
+        unsigned long long total = 0;
+        for (int s = 0; s < spp; ++s) {
+            const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+            f3 o, d;
+            camera_ray(cam, (float)x + u0, (float)y + u1, o, d);
+            uint32_t nd = 2;
+            whitted_li<LDS_SCENE, false, SPH>(sc, tb, stk, o, d, rng, maxDepth, true, cn, nc, na, nd);
+            total += nd;
+        }
+        draws[pi] = total;
+    }
+}
+
+// One lane per tile: exclusive scan of the tile's per-pixel draw counts into offsets; flags any change.
+// firstGuess != 0: instead of reading counts, assume every pixel of the film draws firstGuess numbers.
+__global__ __launch_bounds__(RT_BLOCK) void k_whitted_scan(CameraDev cam, uint32_t nTiles, uint32_t ntx, const unsigned long long *__restrict__ draws,
+                                                           unsigned long long *__restrict__ offsets, unsigned long long firstGuess, uint32_t *tileLive,
+                                                           uint32_t *changed) {
+    const uint32_t t = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (t >= nTiles) return;
+    if (!firstGuess && !tileLive[t]) return;
+    const int sbW = cam.sb[2] - cam.sb[0], sbH = cam.sb[3] - cam.sb[1];
+    unsigned long long run = 0;
+    bool diff = false;
+    for (uint32_t k = 0; k < 256; ++k) {
+        const size_t pi = (size_t)t * 256 + k;
+        unsigned long long dcount;
+        if (firstGuess) {
+            const int lx = (int)(t % ntx) * 16 + (int)(k % 16), ly = (int)(t / ntx) * 16 + (int)(k / 16);
+            dcount = (lx < sbW && ly < sbH) ? firstGuess : 0ull;
+        } else {
+            dcount = draws[pi];
+        }
+        if (firstGuess || offsets[pi] != run) {
+            offsets[pi] = run;
+            diff = true;
+        }
+        run += dcount;
+    }
+    tileLive[t] = diff ? 1u : 0u;
+    if (diff && !firstGuess) atomicOr(changed, 1u);
+}
+
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam, int sppBegin, int sppEnd, int sppTotal, int maxDepth, int rngMode,
                                                       uint64_t seed, const uint2 *pixelState, float *rgbSum, float *weightSum, float *spillRgb,
@@ -877,7 +952,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
     const int sbW = cam.sb[2] - cam.sb[0], sbH = cam.sb[3] - cam.sb[1];
     TravCounters cn = {0, 0, 0, 0};
-    uint32_t nc = 0, na = 0, ns = 0;
+    uint32_t nc = 0, na = 0, ns = 0, ndr = 0;
     // pixels are visited tile by tile (16x16) so that a wave works on a compact screen region
     const uint32_t ntx = (uint32_t)(sbW + 15) / 16, nty = (uint32_t)(sbH + 15) / 16;
     const uint32_t nSlots = ntx * nty * 256u;
@@ -903,7 +978,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam
             const float pfx = (float)px + u0, pfy = (float)py + u1;
             f3 o, d;
             camera_ray(cam, pfx, pfy, o, d);
-            f3 L = whitted_li<LDS_SCENE, STATS, SPH>(sc, tb, stk, o, d, rng, maxDepth, false, cn, nc, na);
+            f3 L = whitted_li<LDS_SCENE, STATS, SPH>(sc, tb, stk, o, d, rng, maxDepth, false, cn, nc, na, ndr);
             L = sanitize_L(L);
             ++ns;
             int fx0, fy0, fx1, fy1;

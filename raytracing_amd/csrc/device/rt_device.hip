@@ -40,6 +40,9 @@ struct rt_context {
     DevScene sc{};
     void *dNodes = nullptr, *dLeafIdx = nullptr, *dTriHot = nullptr, *dTriShade = nullptr, *dMats = nullptr, *dLights = nullptr;
     void *dLightCdf = nullptr, *dLightFunc = nullptr, *dSpheres = nullptr;
+    unsigned long long *dWhittedOffsets = nullptr, *dWhittedDraws = nullptr;   // tile-stream prepass scratch
+    size_t whittedScanCap = 0;
+    int whittedPasses = 0;   // count passes the last tile-stream prepass took (-1: fell back to the serial kernel)
     bool ldsScene = false;
     bool hasSpheres = false;
     bool hasGlass = false;
@@ -412,12 +415,50 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
             HIPCHK(c, hipMalloc((void **)&c->dPixelState, need * sizeof(uint2)));
             c->pixelStateCap = need;
         }
-        auto k = c->hasSpheres ? (c->ldsScene ? k_whitted_prepass<true, true> : k_whitted_prepass<false, true>)
-                               : (c->ldsScene ? k_whitted_prepass<true, false> : k_whitted_prepass<false, false>);
-        // one lane per tile: spread the lanes over many small groups of waves
-        hipLaunchKernelGGL(k, dim3((nTiles + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, c->stream, c->sc, cam, p->spp_total, p->max_depth,
-                           nTiles, ntx, c->dPixelState);
-        HIPCHK(c, hipGetLastError());
+        // parallel fixed point over per-pixel stream offsets (k_whitted_count / k_whitted_scan), serial kernel as fallback
+        const size_t nSlotsPre = (size_t)nTiles * 256;
+        if (c->whittedScanCap < nSlotsPre) {
+            if (c->dWhittedOffsets) (void)hipFree(c->dWhittedOffsets);
+            if (c->dWhittedDraws) (void)hipFree(c->dWhittedDraws);
+            c->dWhittedOffsets = c->dWhittedDraws = nullptr;
+            c->whittedScanCap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->dWhittedOffsets, nSlotsPre * sizeof(unsigned long long) + 256 + (size_t)nTiles * sizeof(uint32_t)));
+            HIPCHK(c, hipMalloc((void **)&c->dWhittedDraws, nSlotsPre * sizeof(unsigned long long)));
+            c->whittedScanCap = nSlotsPre;
+        }
+        uint32_t *dChanged = reinterpret_cast<uint32_t *>(c->dWhittedOffsets + nSlotsPre);
+        uint32_t *dTileLive = dChanged + 64;
+        const int scanGrid = (int)((nTiles + RT_BLOCK - 1) / RT_BLOCK);
+        const int countGrid = (int)std::min<size_t>((nSlotsPre + RT_BLOCK - 1) / RT_BLOCK, (size_t)c->gridBlocks * 4u);
+        // first guess: every sample hits a surface without specular recursion: 2 camera + 2 per light + 2 + 2 (specularReflect / Transmit)
+        const unsigned long long guess = (unsigned long long)p->spp_total * (6ull + 2ull * c->sc.nLights);
+        hipLaunchKernelGGL(k_whitted_scan, dim3(scanGrid), dim3(RT_BLOCK), 0, c->stream, cam, nTiles, ntx, (const unsigned long long *)c->dWhittedDraws,
+                           c->dWhittedOffsets, guess, dTileLive, dChanged);
+        auto kc = c->hasSpheres ? (c->ldsScene ? k_whitted_count<true, true> : k_whitted_count<false, true>)
+                                : (c->ldsScene ? k_whitted_count<true, false> : k_whitted_count<false, false>);
+        bool converged = false;
+        for (int it = 0; it < 64 && !converged; ++it) {
+            HIPCHK(c, hipMemsetAsync(dChanged, 0, sizeof(uint32_t), c->stream));
+            hipLaunchKernelGGL(kc, dim3(countGrid), dim3(RT_BLOCK), lds, c->stream, c->sc, cam, p->spp_total, p->max_depth, nTiles, ntx,
+                               (const unsigned long long *)c->dWhittedOffsets, (const uint32_t *)dTileLive, c->dWhittedDraws, c->dPixelState);
+            hipLaunchKernelGGL(k_whitted_scan, dim3(scanGrid), dim3(RT_BLOCK), 0, c->stream, cam, nTiles, ntx,
+                               (const unsigned long long *)c->dWhittedDraws, c->dWhittedOffsets, 0ull, dTileLive, dChanged);
+            HIPCHK(c, hipGetLastError());
+            uint32_t changed = 1;
+            HIPCHK(c, hipMemcpyAsync(&changed, dChanged, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            converged = changed == 0;
+            c->whittedPasses = it + 1;
+        }
+        if (!converged) {
+            c->whittedPasses = -1;
+            auto k = c->hasSpheres ? (c->ldsScene ? k_whitted_prepass<true, true> : k_whitted_prepass<false, true>)
+                                   : (c->ldsScene ? k_whitted_prepass<true, false> : k_whitted_prepass<false, false>);
+            // one lane per tile: spread the lanes over many small groups of waves
+            hipLaunchKernelGGL(k, dim3((nTiles + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, c->stream, c->sc, cam, p->spp_total, p->max_depth,
+                               nTiles, ntx, c->dPixelState);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     const uint32_t nSlots = nTiles * 256u;
     const int grid = (int)std::min<uint32_t>((nSlots + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)c->gridBlocks * 4u);
@@ -489,6 +530,8 @@ void rt_destroy(rt_context *c) {
     if (c->dSpillRgb) (void)hipFree(c->dSpillRgb);
     if (c->dSpillW) (void)hipFree(c->dSpillW);
     if (c->dPixelState) (void)hipFree(c->dPixelState);
+    if (c->dWhittedOffsets) (void)hipFree(c->dWhittedOffsets);
+    if (c->dWhittedDraws) (void)hipFree(c->dWhittedDraws);
     for (auto &ep : c->extendEvents) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -879,6 +922,7 @@ int rt_reset_stats(rt_context *c) {
 // Host-side evaluation of the device's trigonometric helpers (they are __host__ __device__): lets a CPU test compare
 // them with a double-precision libm without a GPU.
 void rt_debug_sincos_disk(float theta, float *s, float *c) { sincos_disk(theta, *s, *c); }
+int rt_debug_whitted_passes(const rt_context *c) { return c ? c->whittedPasses : 0; }
 void rt_debug_sincos_cr(float theta, float *s, float *c) { sincos_cr(theta, *s, *c); }
 
 }  // extern "C"
