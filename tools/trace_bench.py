@@ -41,11 +41,11 @@ def main():
         ctx.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    def run(name, o, d):
+    def run(name, o, d, schedules=(False, True)):
         o = o.contiguous()
         d = d.contiguous()
         torch.cuda.synchronize()
-        for stream in (False, True):
+        for stream in schedules:
             ctx.set_trace_schedule("stream" if stream else "lockstep")
             run1(name + (" stream" if stream else " lockstep"), o, d)
 
@@ -91,6 +91,15 @@ def main():
     octant = (dhemi[:, 0] > 0).int() + 2 * (dhemi[:, 1] > 0).int() + 4 * (dhemi[:, 2] > 0).int()
     order = torch.sort(octant, stable=True).indices
     run("inward/oct", p[order], dhemi[order])
+
+    # grouping inside windows of w consecutive rays only (what a workgroup could do on the fly), and a finer key
+    idx = torch.arange(n, device=dev)
+    for w in (256, 1024, 4096):
+        order = torch.sort((idx // w) * 8 + octant, stable=True).indices
+        run(f"inward/oct{w}", p[order], dhemi[order], schedules=(False,))
+    major = torch.argmax(dhemi.abs(), dim=1).int()
+    order = torch.sort(octant * 3 + major, stable=True).indices
+    run("inward/oct+axis", p[order], dhemi[order], schedules=(False,))
 
     o, d = raygen.incoherent_rays(scene.bounds, n, 3)
     run("uniform", torch.tensor(o, device=dev), torch.tensor(d, device=dev))
