@@ -54,3 +54,25 @@ def triangle_soup(n_tris, seed, lo=50.0, hi=500.0, emin=0.5, emax=5.0):
     e /= np.linalg.norm(e, axis=2, keepdims=True)
     e *= rs.uniform(emin, emax, (n_tris, 3, 1))
     return (c + e).astype(np.float32).reshape(n_tris, 9)
+
+
+def displaced_grid(nx, nz, seed, lo=0.0, hi=556.0, base=120.0, amp=45.0):
+    """Height field over [lo,hi]^2 tessellated into nx x nz cells of two triangles: a few octaves of sines plus
+    per-vertex noise, so neighbouring triangles are connected but not coplanar. Returns (tri[n,9], stripe[n]) with
+    stripe in [0,1): the cell's position across x, for assigning materials by stripe."""
+    rs = np.random.RandomState(seed)
+    x = np.linspace(lo, hi, nx + 1)
+    z = np.linspace(lo, hi, nz + 1)
+    gx, gz = np.meshgrid(x, z, indexing="ij")
+    y = np.full_like(gx, base)
+    for k in range(1, 6):
+        fx, fz, ph = rs.uniform(0.5, 1.5) * k, rs.uniform(0.5, 1.5) * k, rs.uniform(0, 2 * np.pi, 2)
+        y += amp / k * np.sin(2 * np.pi * fx * gx / (hi - lo) + ph[0]) * np.cos(2 * np.pi * fz * gz / (hi - lo) + ph[1])
+    y += rs.uniform(-0.02, 0.02, y.shape) * (hi - lo) / max(nx, nz) * 4
+    v = np.stack([gx, y, gz], 2).astype(np.float32)
+    a, b, c, d = v[:-1, :-1], v[1:, :-1], v[1:, 1:], v[:-1, 1:]
+    t0 = np.concatenate([a, c, b], 2).reshape(-1, 9)   # wound so that the geometric normals point up
+    t1 = np.concatenate([a, d, c], 2).reshape(-1, 9)
+    tri = np.stack([t0, t1], 1).reshape(-1, 9)
+    stripe = np.repeat((np.arange(nx, dtype=np.float64) / nx)[:, None], nz, 1).reshape(-1)
+    return np.ascontiguousarray(tri, np.float32), np.repeat(stripe, 2)

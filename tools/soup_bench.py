@@ -16,7 +16,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from raytracing_amd.device import Context  # noqa: E402
-from raytracing_amd.scene import FlatScene, build_scene, make_lights, make_materials  # noqa: E402
+from raytracing_amd.scene import FlatScene, build_scene, camera_ray, make_lights, make_materials  # noqa: E402
 import raygen  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
@@ -39,6 +39,10 @@ def main():
     build_s = time.perf_counter() - t0
     print(f"# soup: {n_tris} triangles, {len(scene.nodes)} nodes, {len(scene.leaf_idx)} leaf indices, build {build_s:.1f} s "
           f"({scene.tree_stats})", flush=True)
+    measure(scene, cfg, f"{n_tris}-triangle soup", n, reps, 15)
+
+
+def measure(scene, cfg, label, n, reps, depth):
     ctx = Context(0)
     ctx.upload_scene(scene)
     dev = torch.device("cuda", 0)
@@ -57,16 +61,16 @@ def main():
 
     def run(name, o_np, d_np):
         # per-ray work from the instrumented kernels on a sample of the batch
-        m = min(len(o_np), 200_000)
+        step = max(1, len(o_np) // 200_000)
         ctx.reset_stats()
-        ctx.trace_closest(o_np[:m], d_np[:m])
+        ctx.trace_closest(np.ascontiguousarray(o_np[::step]), np.ascontiguousarray(d_np[::step]))
         st = ctx.stats()
         cr = max(1, st["counted_rays"])
         ni, nl, nidx, ntri = st["n_interior"] / cr, st["n_leaf"] / cr, st["n_leaf_idx"] / cr, st["n_tri_tests"] / cr
         bpr = 28 + 16 + 8 * (ni + nl) + 4 * nidx + 36 * ntri
         o = torch.tensor(o_np, device=dev)
         d = torch.tensor(d_np, device=dev)
-        out = {"workload": f"{n_tris}-triangle soup, {name} rays", "n_rays": n,
+        out = {"workload": f"{label}, {name} rays", "n_rays": n,
                "per_ray": {"interior": ni, "leaf": nl, "leaf_idx": nidx, "tri_tests": ntri}, "bytes_per_ray": bpr}
         for stream in (False, True):
             ctx.set_trace_schedule("stream" if stream else "lockstep")
@@ -78,13 +82,14 @@ def main():
         out["hit_fraction"] = float((prim >= 0).float().mean())
         print(json.dumps(out), flush=True)
 
-    # primary rays: pinhole in front of the cube, regular grid of directions in scanline order
+    # primary rays: the camera's pinhole, regular grid of film positions in scanline order
     side = int(np.sqrt(n))
     u = (np.arange(side, dtype=np.float32) + 0.5) / side
     gx, gy = np.meshgrid(u, u)
-    target = np.stack([50 + 450 * gx.ravel(), 50 + 450 * gy.ravel(), np.full(side * side, 275, np.float32)], 1).astype(np.float32)
-    eye = np.array([275, 275, -600], np.float32)
-    d = target - eye
+    eye, d00 = [np.asarray(v, np.float32) for v in camera_ray(cfg, 0.5, 0.5)]
+    d10 = np.asarray(camera_ray(cfg, cfg.width - 0.5, 0.5)[1], np.float32)
+    d01 = np.asarray(camera_ray(cfg, 0.5, cfg.height - 0.5)[1], np.float32)
+    d = d00 + gx.reshape(-1, 1) * (d10 - d00) + gy.reshape(-1, 1) * (d01 - d00)
     d /= np.sqrt((d * d).sum(1, keepdims=True)).astype(np.float32)
     if len(d) < n:
         d = np.concatenate([d, d[: n - len(d)]])
@@ -93,24 +98,24 @@ def main():
     o, d = raygen.incoherent_rays(scene.bounds, n, 3)
     run("incoherent", o, d)
 
-    # path tracing (PathRenderer::Li, depth 15) at 1920x1080, 4 spp
+    # path tracing (PathRenderer::Li) at 1920x1080, 16 spp
     ctx.set_camera(cfg)
     rgb = torch.zeros((cfg.height, cfg.width, 3), dtype=torch.float32, device=dev)
     w = torch.zeros((cfg.height, cfg.width), dtype=torch.float32, device=dev)
     for schedule in ("lockstep", "stream"):
         ctx.set_trace_schedule(schedule)
-        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=4, max_depth=15)
+        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=16, max_depth=depth)
         ctx.synchronize()
         rgb.zero_()
         w.zero_()
         ctx.reset_stats()
         t0 = time.perf_counter()
-        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=4, max_depth=15)
+        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=16, max_depth=depth)
         ctx.synchronize()
         dt = time.perf_counter() - t0
         st = ctx.stats()
         rays = st["rays_closest"] + st["rays_any"]
-        print(json.dumps({"workload": f"{n_tris}-triangle soup, PathTracing 1920x1080, 4 spp, depth 15", "schedule": schedule, "seconds": dt,
+        print(json.dumps({"workload": f"{label}, PathTracing 1920x1080, 16 spp, depth {depth}", "schedule": schedule, "seconds": dt,
                           "Mrays_per_s": rays / dt / 1e6, "Msamples_per_s": st["camera_samples"] / dt / 1e6,
                           "rays_per_sample": rays / max(1, st["camera_samples"]), "extend_ms": st["extend_ms"],
                           "mean_rgb": [float(v) for v in (rgb.sum((0, 1)) / w.sum()).cpu()]}), flush=True)
