@@ -336,24 +336,61 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
     uint32_t *cntNext = &pb.counts[cnt_index(bounce + 1, 0)];
     uint32_t *cntShadow = &pb.counts[cnt_index(bounce, 1)];
     uint32_t *cntProbe = &pb.counts[cnt_index(bounce, 2)];
-    const uint32_t nRound = (n + RT_BLOCK - 1u) & ~(RT_BLOCK - 1u);   // whole blocks enter the loop: the append synchronises
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < nRound; i += gridDim.x * RT_BLOCK) {
-        bool alive = i < n;
+    // Rays that missed have nothing to shade. The block reads hit records 256 at a time, keeps the slots of the hits
+    // in a ring in LDS and shades 256 of them at a time, so that (but for the block's last round) every lane has work.
+    __shared__ uint32_t s_fill[8];
+    __shared__ uint32_t s_slot[2 * RT_BLOCK];
+    __shared__ float4 s_hit[2 * RT_BLOCK];
+    const uint32_t nChunks = (n + RT_BLOCK - 1u) / RT_BLOCK;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    uint32_t chunk = blockIdx.x, head = 0, pending = 0, parity = 0;   // the same in every thread of the block
+    for (;;) {
+        while (pending < RT_BLOCK && chunk < nChunks) {
+            const uint32_t j = chunk * RT_BLOCK + threadIdx.x;
+            chunk += gridDim.x;
+            float4 hj = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool isHit = false;
+            if (j < n) {
+                hj = pb.hit[j];
+                isHit = __float_as_int(hj.x) >= 0;
+            }
+            const unsigned long long m = __ballot(isHit);
+            if (lane == 0) s_fill[parity * 4 + wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t pre = 0, total = 0;
+            for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) {
+                const uint32_t cw = s_fill[parity * 4 + w];
+                pre += w < wave ? cw : 0u;
+                total += cw;
+            }
+            if (isHit) {
+                const uint32_t e = (head + pending + pre + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (2 * RT_BLOCK - 1u);
+                s_slot[e] = j;
+                s_hit[e] = hj;
+            }
+            pending += total;
+            parity ^= 1u;   // the next round's counts go to the other half: one barrier per round is enough
+        }
+        if (pending == 0) break;
+        const uint32_t take = pending < RT_BLOCK ? pending : RT_BLOCK;
+        __syncthreads();   // ring entries written above are visible
+        bool alive = false;   // set when the path continues
         bool wantShadow = false;
         float4 sA, sB, sC;          // shadow entry
         float4 nA, nB;              // next ray
         sA = sB = sC = nA = nB = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (alive) {
+        if (threadIdx.x < take) {
+            const uint32_t e = (head + threadIdx.x) & (2 * RT_BLOCK - 1u);
+            const uint32_t i = s_slot[e];
+            const float4 hr = s_hit[e];
             const float4 rb = pb.rayB[cur][i];
             const float4 ra = SPH ? pb.rayA[cur][i] : make_float4(0.f, 0.f, 0.f, 0.f);   // only a sphere hit needs the origin
-            const float4 hr = pb.hit[i];
             const uint32_t idBits = __float_as_uint(rb.w);
             const uint32_t pathId = idBits & 0x7fffffffu;
             const bool specularBounce = (idBits >> 31) != 0;
             const f3 rd = mk3(rb.x, rb.y, rb.z);
             const int prim = __float_as_int(hr.x);
-            alive = false;   // set again when the path continues
-            if (prim >= 0) {
+            {
                 Surf sf;
                 surface_at<SPH>(sc, prim, hr.y, hr.z, hr.w, mk3(ra.x, ra.y, ra.z), rd, sf);
                 float4 L4 = pb.L[pathId];
@@ -479,6 +516,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                 if (Ldirty) pb.L[pathId] = L4;
             }
         }
+        head += take;
+        pending -= take;
         uint32_t slotN, slotS;
         block_append2(s_app, cntNext, cntShadow, alive, wantShadow, slotN, slotS);
         if (alive) { pb.rayA[nxt][slotN] = nA; pb.rayB[nxt][slotN] = nB; }
