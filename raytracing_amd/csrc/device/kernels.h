@@ -251,8 +251,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(CameraDev cam, PassInfo ps,
         pb.rayA[0][id] = make_float4(o.x, o.y, o.z, 0.f);
         pb.rayB[0][id] = make_float4(d.x, d.y, d.z, __uint_as_float(id));
         pb.L[id] = make_float4(0.f, 0.f, 0.f, 1.f);
-        pb.beta[id] = make_float4(1.f, 1.f, 1.f, 0.f);
-        pb.rng[id] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
+        // beta = 1 and the generator's state after the two film draws are rebuilt by k_shade at bounce 0 (half of the
+        // camera rays of a 16:9 cornellBox frame miss and never need them)
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         pb.counts[cnt_index(0, 0)] = n;
@@ -394,8 +394,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                 Surf sf;
                 surface_at<SPH>(sc, prim, hr.y, hr.z, hr.w, mk3(ra.x, ra.y, ra.z), rd, sf);
                 float4 L4 = pb.L[pathId];
-                const float4 beta4 = pb.beta[pathId];
-                f3 beta = mk3(beta4.x, beta4.y, beta4.z);
+                f3 beta = mk3(1.f, 1.f, 1.f);
+                if (bounce > 0) {
+                    const float4 beta4 = pb.beta[pathId];
+                    beta = mk3(beta4.x, beta4.y, beta4.z);
+                }
                 float etaScale = L4.w;
                 bool Ldirty = false;
                 if ((bounce == 0 || specularBounce) && sf.light >= 0) {
@@ -408,9 +411,20 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                     DBsdf bs;
                     bsdf_init<MATSET>(bs, sf, sc.mats[sf.mat]);
                     Pcg rng;
-                    const uint4 st = pb.rng[pathId];
-                    rng.state = (uint64_t)st.x | ((uint64_t)st.y << 32);
-                    rng.inc = (uint64_t)st.z | ((uint64_t)st.w << 32);
+                    uint4 st;
+                    if (bounce > 0) {
+                        st = pb.rng[pathId];
+                        rng.state = (uint64_t)st.x | ((uint64_t)st.y << 32);
+                        rng.inc = (uint64_t)st.z | ((uint64_t)st.w << 32);
+                    } else {   // the stream k_raygen drew the film position from
+                        int px, py;
+                        uint32_t sLocal;
+                        pcg_set_sequence(rng, path_sequence(cam, ps, pathId, px, py, sLocal));
+                        (void)pcg_float(rng);
+                        (void)pcg_float(rng);
+                        st.z = (uint32_t)rng.inc;
+                        st.w = (uint32_t)(rng.inc >> 32);
+                    }
                     const f3 isectWo = normalize3(-rd);
 
                     if (bsdf_num(bs, BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.nLights > 0) {
