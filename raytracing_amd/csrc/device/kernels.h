@@ -26,6 +26,14 @@ RT_DEV void camera_ray(const CameraDev &cam, float fx, float fy, f3 &o, f3 &d) {
     d = normalize3(xf_apply(cam.c2w, dir, 0.0f));
 }
 
+// Origin of every camera ray (APerspectiveCamera::castingRay, Camera/Camera.cpp:87-95, starts all rays at the
+// camera-space origin): the value camera_ray returns as `o` for any film position.
+RT_DEV float4 camera_origin(const CameraDev &cam) {
+    f3 o, d;
+    camera_ray(cam, 0.f, 0.f, o, d);
+    return make_float4(o.x, o.y, o.z, 0.f);
+}
+
 RT_DEV void flush_counters(unsigned long long *stats, const TravCounters &cn, uint32_t rays) {
     atomicAdd(&stats[ST_INTERIOR], (unsigned long long)cn.interior);
     atomicAdd(&stats[ST_LEAF], (unsigned long long)cn.leaf);
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(CameraDev cam, PassInfo ps,
         const float u0 = pcg_float(rng), u1 = pcg_float(rng);
         f3 o, d;
         camera_ray(cam, (float)px + u0, (float)py + u1, o, d);
-        pb.rayA[0][id] = make_float4(o.x, o.y, o.z, 0.f);
+        // every camera ray starts at the pinhole: no origin records at bounce 0 (camera_origin)
         pb.rayB[0][id] = make_float4(d.x, d.y, d.z, __uint_as_float(id));
         pb.L[id] = make_float4(0.f, 0.f, 0.f, 1.f);
         // beta = 1 and the generator's state after the two film draws are rebuilt by k_shade at bounce 0 (half of the
@@ -262,7 +270,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(CameraDev cam, PassInfo ps,
 
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
-                                                     float4 *__restrict__ hit, const uint32_t *__restrict__ count, unsigned long long *stats) {
+                                                     float4 *__restrict__ hit, const uint32_t *__restrict__ count, unsigned long long *stats,
+                                                     float4 commonOrigin) {
+    // rayA == nullptr: all rays start at commonOrigin (camera rays)
     extern __shared__ uint4 smem[];
     const uint32_t n = *count;
     if (blockIdx.x * RT_BLOCK >= n) return;   // whole block idle: skip the LDS staging
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
     TravCounters cn = {0, 0, 0, 0, 0};
     uint32_t myRays = 0;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        const float4 a = rayA[i], b = rayB[i];
+        const float4 a = rayA ? rayA[i] : commonOrigin, b = rayB[i];
         RayCtx r;
         ray_setup(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z));
         HitRec h;
@@ -292,8 +302,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
 struct ExtendJob {
     const float4 *rayA, *rayB;
     float4 *hit;
+    float4 commonOrigin;   // used when rayA is null
     RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
-        const float4 a = rayA[j], b = rayB[j];
+        const float4 a = rayA ? rayA[j] : commonOrigin, b = rayB[j];
         ro = mk3(a.x, a.y, a.z);
         rd = mk3(b.x, b.y, b.z);
         tm = RT_INF;
@@ -305,14 +316,14 @@ struct ExtendJob {
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_stream(DevScene sc, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
                                                             float4 *__restrict__ hit, const uint32_t *__restrict__ count,
-                                                            unsigned long long *stats) {
+                                                            unsigned long long *stats, float4 commonOrigin) {
     extern __shared__ uint4 smem[];
     const uint32_t n = *count;
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
     TravCounters cn = {0, 0, 0, 0, 0};
-    ExtendJob job = {rayA, rayB, hit};
+    ExtendJob job = {rayA, rayB, hit, commonOrigin};
     trace_stream<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
                                                                       job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
@@ -384,7 +395,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
             const uint32_t i = s_slot[e];
             const float4 hr = s_hit[e];
             const float4 rb = pb.rayB[cur][i];
-            const float4 ra = SPH ? pb.rayA[cur][i] : make_float4(0.f, 0.f, 0.f, 0.f);   // only a sphere hit needs the origin
+            // only a sphere hit needs the origin
+            const float4 ra = SPH ? (bounce > 0 ? pb.rayA[cur][i] : camera_origin(cam)) : make_float4(0.f, 0.f, 0.f, 0.f);
             const uint32_t idBits = __float_as_uint(rb.w);
             const uint32_t pathId = idBits & 0x7fffffffu;
             const bool specularBounce = (idBits >> 31) != 0;

@@ -331,6 +331,12 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     const bool streamTrace = use_stream_schedule(c);
     const int pipesInUse = (streamTrace || std::getenv("RT_AMD_SINGLE_PIPE")) ? 1 : rt_context::kPipes;
 
+    // what camera_origin() returns on the device: xf_apply(c2w, (0, 0, 0), 1) with the same operation order
+    float co[4];
+    for (int k = 0; k < 4; ++k) co[k] = (cam.c2w[0 * 4 + k] * 0.f + cam.c2w[1 * 4 + k] * 0.f) + (cam.c2w[2 * 4 + k] * 0.f + cam.c2w[3 * 4 + k] * 1.0f);
+    if (co[3] != 1) for (int k = 0; k < 3; ++k) co[k] = co[k] / co[3];
+    const float4 camOrigin = make_float4(co[0], co[1], co[2], 0.f);
+
     // the pipelines start after everything already queued on the context's stream
     HIPCHK(c, hipEventRecord(c->mainReady, c->stream));
     for (int k = 0; k < rt_context::kPipes; ++k) HIPCHK(c, hipStreamWaitEvent(c->pipeStream[k], c->mainReady, 0));
@@ -353,16 +359,18 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
         hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cam, ps, pb, c->dStats);
         for (int b = 0; b <= p->max_depth; ++b) {
             const int cur = b & 1;
+            // camera rays share their origin and have no origin records
+            auto originsOf = [&](int bounce) { return bounce == 0 ? (const float4 *)nullptr : (const float4 *)pb.rayA[cur]; };
             EventPair *ep = next_event_pair(c);
             if (ep) HIPCHK(c, hipEventRecord(ep->a, st));
             if (streamTrace) {
                 auto kx = RT_PICK(k_extend_stream, c, stats);
-                hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, (const float4 *)pb.rayA[cur],
-                                   (const float4 *)pb.rayB[cur], pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
+                hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, originsOf(b),
+                                   (const float4 *)pb.rayB[cur], pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats, camOrigin);
             } else {
                 auto kx = RT_PICK(k_extend, c, stats);
-                hipLaunchKernelGGL(kx, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, (const float4 *)pb.rayA[cur], (const float4 *)pb.rayB[cur], pb.hit,
-                                   (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats);
+                hipLaunchKernelGGL(kx, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, originsOf(b), (const float4 *)pb.rayB[cur], pb.hit,
+                                   (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats, camOrigin);
             }
             if (ep) HIPCHK(c, hipEventRecord(ep->b, st));
             auto ksh = c->hasSpheres ? (c->allLambert ? k_shade<MATSET_LAMBERT, true> : k_shade<MATSET_ANY, true>)
