@@ -405,7 +405,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
             {
                 Surf sf;
                 surface_at<SPH>(sc, prim, hr.y, hr.z, hr.w, mk3(ra.x, ra.y, ra.z), rd, sf);
-                float4 L4 = pb.L[pathId];
+                // L is read for an emission to add and for etaScale; a scene of Lambertian materials has neither specular
+                // bounces nor refraction (etaScale stays 1), so there only a camera ray that sees a light needs it
+                const bool emits = (bounce == 0 || specularBounce) && sf.light >= 0;
+                float4 L4 = make_float4(0.f, 0.f, 0.f, 1.f);
+                if (MATSET != MATSET_LAMBERT || emits) L4 = pb.L[pathId];
                 f3 beta = mk3(1.f, 1.f, 1.f);
                 if (bounce > 0) {
                     const float4 beta4 = pb.beta[pathId];
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                 }
                 float etaScale = L4.w;
                 bool Ldirty = false;
-                if ((bounce == 0 || specularBounce) && sf.light >= 0) {
+                if (emits) {
                     const f3 le = light_L(sc.lights[sf.light], sf.n, -rd);
                     const f3 add = beta * le;
                     L4.x += add.x; L4.y += add.y; L4.z += add.z;
