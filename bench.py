@@ -30,10 +30,10 @@ MAX_DEPTH = 15
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 FP32_VALU_PEAK_TFLOPS = 157.3
 # HBM-side bytes per ray of k_extend from the hardware counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes over this workload, profiles/r01_pmc_bench_steps4.md): 2 x 17.2 B read (gfx950 counts the 16-B-per-lane
-# coalesced reads at half their bytes) + 17.5 B written. Counters cannot be read inside a timed run, so the figure
-# measured under the profiler is scaled by this run's rays per launch.
-EXTEND_HBM_BYTES_PER_RAY_PMC = 52.0
+# passes over this workload, profiles/r01_pmc_bench_steps4_v13.md): 2 x 13.5 B read (gfx950 counts the 16-B-per-lane
+# coalesced reads at half their bytes; camera rays have no origin record) + 17.0 B written. Counters cannot be read
+# inside a timed run, so the figure measured under the profiler is scaled by this run's rays per launch.
+EXTEND_HBM_BYTES_PER_RAY_PMC = 44.0
 
 
 def bytes_per_ray(ni, nl, nidx, ntri, closest=True):
