@@ -159,6 +159,14 @@ int rt_upload_scene(rt_context *ctx, const rt_scene_desc *scene);
 int rt_set_camera(rt_context *ctx, const float raster_to_camera[16], const float camera_to_world[16],
                   int width, int height, const int sample_bounds[4]);
 
+/* Film parameters that differ from what rt_set_camera installs (0.5 box filter, cropped pixel bounds = sample bounds
+ * clipped to the film, no clamp): the Box filter's "Radius" (Render/Filter.cpp:4-24; the reference's only filter, weight 1
+ * inside the radius), Film::m_croppedPixelBounds (Object/Film.cpp:21-24) - only these pixels receive samples
+ * (Film::getFilmTile, :87-96; FilmTile::addSample, Object/Film.h:111-155) - and "MaxLum" (Film.cpp:30, Film.h:113-115;
+ * pass INFINITY for none). The sample bounds given to rt_set_camera must be Film::getSampleBounds for this radius and
+ * crop (Film.cpp:79-85). Call after rt_set_camera; a later rt_set_camera resets the defaults. */
+int rt_set_film(rt_context *ctx, float radius_x, float radius_y, const int cropped_bounds[4], float max_sample_luminance);
+
 /* Batch tracing --------------------------------------------------------------------------------- */
 
 /* Closest hit: KdTree::hit(ray, isect) (Accelerators/KDTree.cpp:385-490) over n rays. d is used as

@@ -38,6 +38,7 @@ typedef struct rt_host_config {
     float camera_to_world[16];
     float fov, eye[3], focus[3], up[3];
     char filename[256];        /* Film "Filename" */
+    float max_sample_luminance; /* Film "MaxLum", default +inf (Object/Film.cpp:30) */
 } rt_host_config;
 
 /* KD-tree shape numbers, for checking a build against known answers. */

@@ -186,6 +186,10 @@ struct Scene {
     // camera
     float r2c[16], c2w[16];
     int width = 0, height = 0, sb[4] = {0, 0, 0, 0};
+    // Film: Box filter radius (Render/Filter.cpp:4-24), cropped pixel bounds (Object/Film.cpp:21-24), MaxLum (:30)
+    float filterRadius[2] = {0.5f, 0.5f};
+    int cb[4] = {0, 0, 0, 0};
+    float maxSampleLuminance = std::numeric_limits<float>::infinity();
     bool hasCamera = false;
 
     vec3 P(int prim, int k) const { const float *p = &triP[9 * prim + 3 * k]; return vec3(p[0], p[1], p[2]); }
@@ -1103,7 +1107,21 @@ int oracle_set_camera(oracle_scene *o, const float r2c[16], const float c2w[16],
     o->s.width = width;
     o->s.height = height;
     std::memcpy(o->s.sb, sb, 16);
+    // defaults of the film: 0.5 box filter, for which the sample bounds are the cropped pixel bounds; no clamp
+    o->s.filterRadius[0] = o->s.filterRadius[1] = 0.5f;
+    std::memcpy(o->s.cb, sb, 16);
+    o->s.maxSampleLuminance = std::numeric_limits<float>::infinity();
     o->s.hasCamera = true;
+    return 0;
+}
+
+// Film parameters that differ from the defaults above (Object/Film.cpp:17-37).
+int oracle_set_film(oracle_scene *o, float radius_x, float radius_y, const int cropped_bounds[4], float max_sample_luminance) {
+    if (!o || !cropped_bounds || !o->s.hasCamera || !(radius_x > 0) || !(radius_y > 0)) return -1;
+    o->s.filterRadius[0] = radius_x;
+    o->s.filterRadius[1] = radius_y;
+    std::memcpy(o->s.cb, cropped_bounds, 16);
+    o->s.maxSampleLuminance = max_sample_luminance;
     return 0;
 }
 
@@ -1197,9 +1215,11 @@ int oracle_render(const oracle_scene *o, const rt_render_params *p, float *rgb_s
             int tx = t % ntx, ty = t / ntx;
             int x0 = s.sb[0] + tx * tileSize, x1 = std::min(x0 + tileSize, s.sb[2]);
             int y0 = s.sb[1] + ty * tileSize, y1 = std::min(y0 + tileSize, s.sb[3]);
-            // tile film: the tile's pixels plus a one-pixel border (Film::getFilmTile for radius 0.5), clipped to the film
-            int fx0 = std::max(x0 - 1, 0), fy0 = std::max(y0 - 1, 0), fx1 = std::min(x1 + 1, s.width), fy1 = std::min(y1 + 1, s.height);
-            int fw = fx1 - fx0, fh = fy1 - fy0;
+            // tile film: Film::getFilmTile (Object/Film.cpp:87-96): the pixels the tile's samples can reach, inside the crop
+            const float frx = s.filterRadius[0], fry = s.filterRadius[1];
+            int fx0 = std::max((int)std::ceil((float)x0 - 0.5f - frx), s.cb[0]), fy0 = std::max((int)std::ceil((float)y0 - 0.5f - fry), s.cb[1]);
+            int fx1 = std::min((int)std::floor((float)x1 - 0.5f + frx) + 1, s.cb[2]), fy1 = std::min((int)std::floor((float)y1 - 0.5f + fry) + 1, s.cb[3]);
+            int fw = std::max(fx1 - fx0, 0), fh = std::max(fy1 - fy0, 0);
             trgb.assign((size_t)fw * fh * 3, 0.f);
             tw.assign((size_t)fw * fh, 0.f);
             Sampler sampler;
@@ -1222,9 +1242,12 @@ int oracle_render(const oracle_scene *o, const rt_render_params *p, float *rgb_s
                         L = sanitize(L);
                         // accumulate into the tile film (offset coordinates), clipped like FilmTile::addSample
                         {
+                            // FilmTile::addSample (Object/Film.h:111-155); the Box filter's table holds 1 everywhere
+                            float lum = 0.212671f * L.c[0] + 0.715160f * L.c[1] + 0.072169f * L.c[2];
+                            if (lum > s.maxSampleLuminance) L = L * (s.maxSampleLuminance / lum);
                             float dx = pfx - 0.5f, dy = pfy - 0.5f;
-                            int ax0 = (int)std::ceil(dx - 0.5f), ay0 = (int)std::ceil(dy - 0.5f);
-                            int ax1 = (int)std::floor(dx + 0.5f) + 1, ay1 = (int)std::floor(dy + 0.5f) + 1;
+                            int ax0 = (int)std::ceil(dx - frx), ay0 = (int)std::ceil(dy - fry);
+                            int ax1 = (int)std::floor(dx + frx) + 1, ay1 = (int)std::floor(dy + fry) + 1;
                             ax0 = std::max(ax0, fx0); ay0 = std::max(ay0, fy0);
                             ax1 = std::min(ax1, fx1); ay1 = std::min(ay1, fy1);
                             for (int yy = ay0; yy < ay1; ++yy)

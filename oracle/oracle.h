@@ -24,6 +24,9 @@ typedef struct oracle_render_stats {
 oracle_scene *oracle_create(const rt_scene_desc *d);
 void oracle_destroy(oracle_scene *o);
 int oracle_set_camera(oracle_scene *o, const float r2c[16], const float c2w[16], int width, int height, const int sb[4]);
+/* Film parameters other than the defaults oracle_set_camera installs (0.5 box filter, crop = sample bounds, no clamp):
+ * Filter "Radius", Film::m_croppedPixelBounds, "MaxLum" (Object/Film.cpp:17-37). */
+int oracle_set_film(oracle_scene *o, float radius_x, float radius_y, const int cropped_bounds[4], float max_sample_luminance);
 int oracle_trace_closest(const oracle_scene *o, uint64_t n, const float *oxyz, const float *dxyz, const float *tmax,
                          int32_t *prim, float *t, float *bary, oracle_counters *counters);
 int oracle_trace_any(const oracle_scene *o, uint64_t n, const float *oxyz, const float *dxyz, const float *tmax,

@@ -99,6 +99,7 @@ class RtHostConfig(C.Structure):
         ("focus", C.c_float * 3),
         ("up", C.c_float * 3),
         ("filename", C.c_char * 256),
+        ("max_sample_luminance", C.c_float),
     ]
 
 

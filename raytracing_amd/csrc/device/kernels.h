@@ -16,6 +16,10 @@ struct CameraDev {
     float r2c[16], c2w[16];
     int width, height;
     int sb[4];   // sample bounds x0,y0,x1,y1
+    // film: Box filter radius, cropped pixel bounds x0,y0,x1,y1 (only these pixels receive samples), MaxLum clamp
+    float filterRadius[2];
+    int cb[4];
+    float maxSampleLuminance;
 };
 
 // APerspectiveCamera::castingRay (Camera/Camera.cpp:87-95): three normalisations, as the reference's Ray constructor does.
@@ -693,20 +697,27 @@ RT_DEV f3 sanitize_L(f3 L) {
     return L;
 }
 
-// FilmTile::addSample for the 0.5-radius box filter (Object/Film.h:111-155): pixels [x0,x1) x [y0,y1)
-// receive L with weight 1. Returns true when that set is exactly the sample's own pixel.
-RT_DEV bool film_footprint(float pfx, float pfy, int px, int py, int &x0, int &y0, int &x1, int &y1) {
+// FilmTile::addSample for the Box filter (Object/Film.h:111-155; the filter table holds 1 everywhere, Render/Filter.cpp:20-23):
+// pixels [x0,x1) x [y0,y1), clipped to the cropped pixel bounds, receive L with weight 1. Returns true when that set is
+// exactly the sample's own pixel (always, for radius 0.5, unless a jitter is exactly 0).
+RT_DEV bool film_footprint(const CameraDev &cam, float pfx, float pfy, int px, int py, int &x0, int &y0, int &x1, int &y1) {
     const float dx = pfx - 0.5f, dy = pfy - 0.5f;
-    x0 = (int)ceilf(dx - 0.5f);
-    y0 = (int)ceilf(dy - 0.5f);
-    x1 = (int)floorf(dx + 0.5f) + 1;
-    y1 = (int)floorf(dy + 0.5f) + 1;
+    x0 = max((int)ceilf(dx - cam.filterRadius[0]), cam.cb[0]);
+    y0 = max((int)ceilf(dy - cam.filterRadius[1]), cam.cb[1]);
+    x1 = min((int)floorf(dx + cam.filterRadius[0]) + 1, cam.cb[2]);
+    y1 = min((int)floorf(dy + cam.filterRadius[1]) + 1, cam.cb[3]);
     return x0 == px && y0 == py && x1 == px + 1 && y1 == py + 1;
+}
+// "MaxLum" of the film (Object/Film.h:113-115)
+RT_DEV f3 film_clamp(const CameraDev &cam, f3 L) {
+    const float lum = 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z;
+    if (lum > cam.maxSampleLuminance) L = L * (cam.maxSampleLuminance / lum);
+    return L;
 }
 RT_DEV void film_spill(const CameraDev &cam, float *spillRgb, float *spillW, int px, int py, int x0, int y0, int x1, int y1, f3 L,
                        f3 &own, float &ownW) {
-    for (int y = max(y0, 0); y < min(y1, cam.height); ++y)
-        for (int x = max(x0, 0); x < min(x1, cam.width); ++x) {
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
             if (x == px && y == py) { own = own + L; ownW += 1.0f; continue; }
             const size_t g = (size_t)y * cam.width + x;
             atomicAdd(&spillRgb[3 * g + 0], L.x);
@@ -722,27 +733,36 @@ __global__ __launch_bounds__(RT_BLOCK) void k_film_path(CameraDev cam, PassInfo 
     for (uint32_t pi = blockIdx.x * RT_BLOCK + threadIdx.x; pi < ps.nPix; pi += gridDim.x * RT_BLOCK) {
         const uint32_t ly = pi / ps.sbW, lx = pi - ly * ps.sbW;
         const int px = cam.sb[0] + (int)lx, py = cam.sb[1] + (int)ly;
-        const size_t g = (size_t)py * cam.width + px;
-        f3 acc = mk3(rgbSum[3 * g], rgbSum[3 * g + 1], rgbSum[3 * g + 2]);
-        float w = weightSum[g];
+        // with a filter radius above 0.5 the sample bounds reach outside the cropped pixel bounds: such a pixel has
+        // samples but no film entry of its own
+        const bool onFilm = px >= cam.cb[0] && px < cam.cb[2] && py >= cam.cb[1] && py < cam.cb[3];
+        const size_t g = onFilm ? (size_t)py * cam.width + px : 0;
+        f3 acc = mk3(0.f, 0.f, 0.f);
+        float w = 0.f;
+        if (onFilm) {
+            acc = mk3(rgbSum[3 * g], rgbSum[3 * g + 1], rgbSum[3 * g + 2]);
+            w = weightSum[g];
+        }
         for (uint32_t s = 0; s < ps.sppPass; ++s) {
             const uint32_t id = s * ps.nPix + pi;
             const float4 L4 = pb.L[id];
-            const f3 L = sanitize_L(mk3(L4.x, L4.y, L4.z));
+            const f3 L = film_clamp(cam, sanitize_L(mk3(L4.x, L4.y, L4.z)));
             const uint64_t pix = (uint64_t)py * (uint64_t)cam.width + (uint64_t)px;
             Pcg rng;
             pcg_set_sequence(rng, counter_sequence(pix, ps.sppTotal, ps.sppBase + s, ps.seed));
             const float u0 = pcg_float(rng), u1 = pcg_float(rng);
             int x0, y0, x1, y1;
-            if (film_footprint((float)px + u0, (float)py + u1, px, py, x0, y0, x1, y1)) {
+            if (film_footprint(cam, (float)px + u0, (float)py + u1, px, py, x0, y0, x1, y1)) {
                 acc = acc + L;
                 w += 1.0f;
             } else {
                 film_spill(cam, spillRgb, spillW, px, py, x0, y0, x1, y1, L, acc, w);
             }
         }
-        rgbSum[3 * g] = acc.x; rgbSum[3 * g + 1] = acc.y; rgbSum[3 * g + 2] = acc.z;
-        weightSum[g] = w;
+        if (onFilm) {
+            rgbSum[3 * g] = acc.x; rgbSum[3 * g + 1] = acc.y; rgbSum[3 * g + 2] = acc.z;
+            weightSum[g] = w;
+        }
     }
 }
 
@@ -1030,9 +1050,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam
         const int lx = (int)(tile % ntx) * 16 + (int)(inTile % 16), ly = (int)(tile / ntx) * 16 + (int)(inTile / 16);
         if (lx >= sbW || ly >= sbH) continue;
         const int px = cam.sb[0] + lx, py = cam.sb[1] + ly;
-        const size_t g = (size_t)py * cam.width + px;
-        f3 acc = mk3(rgbSum[3 * g], rgbSum[3 * g + 1], rgbSum[3 * g + 2]);
-        float w = weightSum[g];
+        const bool onFilm = px >= cam.cb[0] && px < cam.cb[2] && py >= cam.cb[1] && py < cam.cb[3];
+        const size_t g = onFilm ? (size_t)py * cam.width + px : 0;
+        f3 acc = mk3(0.f, 0.f, 0.f);
+        float w = 0.f;
+        if (onFilm) {
+            acc = mk3(rgbSum[3 * g], rgbSum[3 * g + 1], rgbSum[3 * g + 2]);
+            w = weightSum[g];
+        }
         Pcg rng;
         if (rngMode == RT_RNG_REFERENCE_TILE_STREAM) {
             const uint32_t tIdx = (uint32_t)(ly / 16) * ntx + (uint32_t)(lx / 16);
@@ -1048,18 +1073,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam
             f3 o, d;
             camera_ray(cam, pfx, pfy, o, d);
             f3 L = whitted_li<LDS_SCENE, STATS, SPH>(sc, tb, stk, o, d, rng, maxDepth, false, cn, nc, na, ndr);
-            L = sanitize_L(L);
+            L = film_clamp(cam, sanitize_L(L));
             ++ns;
             int fx0, fy0, fx1, fy1;
-            if (film_footprint(pfx, pfy, px, py, fx0, fy0, fx1, fy1)) {
+            if (film_footprint(cam, pfx, pfy, px, py, fx0, fy0, fx1, fy1)) {
                 acc = acc + L;
                 w += 1.0f;
             } else {
                 film_spill(cam, spillRgb, spillW, px, py, fx0, fy0, fx1, fy1, L, acc, w);
             }
         }
-        rgbSum[3 * g] = acc.x; rgbSum[3 * g + 1] = acc.y; rgbSum[3 * g + 2] = acc.z;
-        weightSum[g] = w;
+        if (onFilm) {
+            rgbSum[3 * g] = acc.x; rgbSum[3 * g + 1] = acc.y; rgbSum[3 * g + 2] = acc.z;
+            weightSum[g] = w;
+        }
     }
     if (STATS) flush_counters(stats, cn, nc + na);
     if (nc) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)nc);

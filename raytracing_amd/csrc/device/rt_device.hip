@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../../include/raytracing_amd.h"
@@ -717,14 +718,38 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
 int rt_set_camera(rt_context *c, const float r2c[16], const float c2w[16], int width, int height, const int sb[4]) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (!r2c || !c2w || !sb || width <= 0 || height <= 0) return fail(c, RT_ERR_INVALID_ARG, "bad camera argument");
-    if (sb[0] < 0 || sb[1] < 0 || sb[2] > width || sb[3] > height || sb[0] > sb[2] || sb[1] > sb[3])
-        return fail(c, RT_ERR_INVALID_ARG, "sample bounds must lie inside the film");
+    // Film::getSampleBounds reaches past the film by ceil(radius - 0.5) pixels (Object/Film.cpp:79-85)
+    constexpr int kMaxOutside = 64;
+    if (sb[0] < -kMaxOutside || sb[1] < -kMaxOutside || sb[2] > width + kMaxOutside || sb[3] > height + kMaxOutside || sb[0] > sb[2] ||
+        sb[1] > sb[3])
+        return fail(c, RT_ERR_INVALID_ARG, "sample bounds must be ordered and lie within 64 pixels of the film");
     std::memcpy(c->cam.r2c, r2c, 64);
     std::memcpy(c->cam.c2w, c2w, 64);
     c->cam.width = width;
     c->cam.height = height;
     std::memcpy(c->cam.sb, sb, 16);
+    // film defaults: 0.5 box filter (sample bounds = cropped pixel bounds), no luminance clamp
+    c->cam.filterRadius[0] = c->cam.filterRadius[1] = 0.5f;
+    c->cam.cb[0] = std::max(sb[0], 0);
+    c->cam.cb[1] = std::max(sb[1], 0);
+    c->cam.cb[2] = std::min(sb[2], width);
+    c->cam.cb[3] = std::min(sb[3], height);
+    c->cam.maxSampleLuminance = std::numeric_limits<float>::infinity();
     c->haveCamera = true;
+    return RT_OK;
+}
+
+int rt_set_film(rt_context *c, float radius_x, float radius_y, const int cb[4], float max_sample_luminance) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!c->haveCamera) return fail(c, RT_ERR_NO_CAMERA, "rt_set_film follows rt_set_camera");
+    if (!cb || !(radius_x > 0) || !(radius_y > 0) || radius_x > 32.f || radius_y > 32.f) return fail(c, RT_ERR_INVALID_ARG, "bad film argument");
+    if (cb[0] < 0 || cb[1] < 0 || cb[2] > c->cam.width || cb[3] > c->cam.height || cb[0] > cb[2] || cb[1] > cb[3])
+        return fail(c, RT_ERR_INVALID_ARG, "cropped pixel bounds must lie inside the film");
+    if (std::isnan(max_sample_luminance)) return fail(c, RT_ERR_INVALID_ARG, "bad film argument");
+    c->cam.filterRadius[0] = radius_x;
+    c->cam.filterRadius[1] = radius_y;
+    std::memcpy(c->cam.cb, cb, 16);
+    c->cam.maxSampleLuminance = max_sample_luminance;
     return RT_OK;
 }
 

@@ -1,6 +1,7 @@
 // Host scene front-end: scene JSON -> flat rt_scene_desc (+ render configuration), camera matrices,
 // film development. See include/rt_host.h for the reference files each entry point restates.
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -254,6 +255,7 @@ static void load_json_impl(const std::string &path, rt_host_scene &S) {
     c.cropped_bounds[0] = std::min(ax, bx); c.cropped_bounds[1] = std::min(ay, by);
     c.cropped_bounds[2] = std::max(ax, bx); c.cropped_bounds[3] = std::max(ay, by);
     c.film_scale = fp.getFloat("Scale", 1.0f);
+    c.max_sample_luminance = fp.getFloat("MaxLum", std::numeric_limits<float>::infinity());
     std::string fname = fp.getString("Filename", "rendered.png");
     snprintf(c.filename, sizeof c.filename, "%s", fname.c_str());
     Props flt(fp.child("Filter"));

@@ -15,7 +15,7 @@ _dev = None
 EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_version", "rt_upload_scene", "rt_set_camera", "rt_trace_closest",
     "rt_trace_any", "rt_trace_closest_dev", "rt_trace_any_dev", "rt_render", "rt_render_dev", "rt_synchronize", "rt_stream",
-    "rt_get_stats", "rt_reset_stats", "rt_set_option", "rt_develop", "rt_develop_dev",
+    "rt_get_stats", "rt_reset_stats", "rt_set_option", "rt_develop", "rt_develop_dev", "rt_set_film",
 ]
 
 
@@ -37,6 +37,7 @@ def device_lib():
         lib.rt_version.restype = C.c_char_p
         lib.rt_upload_scene.argtypes = [vp, C.POINTER(RtSceneDesc)]
         lib.rt_set_camera.argtypes = [vp, vp, vp, i32, i32, vp]
+        lib.rt_set_film.argtypes = [vp, C.c_float, C.c_float, vp, C.c_float]
         lib.rt_trace_closest.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
         lib.rt_trace_any.argtypes = [vp, u64, vp, vp, vp, vp]
         lib.rt_trace_closest_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
@@ -105,6 +106,9 @@ class Context:
         c2w = np.ascontiguousarray(cfg.camera_to_world, np.float32)
         sb = np.array(cfg.sample_bounds, np.int32)
         self._check(self._lib.rt_set_camera(self._h, r2c.ctypes.data, c2w.ctypes.data, cfg.width, cfg.height, sb.ctypes.data))
+        cb = np.array(cfg.cropped_bounds, np.int32)
+        self._check(self._lib.rt_set_film(self._h, C.c_float(cfg.filter_radius[0]), C.c_float(cfg.filter_radius[1]), cb.ctypes.data,
+                                          C.c_float(cfg.max_sample_luminance)))
         self.config = cfg
 
     # -- batch tracing (host arrays) ----------------------------------------------------------------

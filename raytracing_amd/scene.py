@@ -6,7 +6,7 @@ plus (when it came from a scene file) the render configuration the reference's R
 """
 import ctypes as C
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace
 from typing import Optional
 
 import numpy as np
@@ -63,13 +63,33 @@ class RenderConfig:
     focus: tuple = (0.0, 0.0, 1.0)
     up: tuple = (0.0, 1.0, 0.0)
     filename: str = "rendered.png"
+    filter_radius: tuple = (0.5, 0.5)
+    max_sample_luminance: float = float("inf")
 
     def with_resolution(self, width, height, spp=None):
-        """Same camera at another film resolution (full crop window, 0.5 box filter)."""
+        """Same camera and filter at another film resolution (full crop window)."""
         r2c, c2w = camera_matrices(self.fov, self.eye, self.focus, self.up, width, height)
+        crop = (0, 0, width, height)
         return RenderConfig(self.integrator, self.max_depth, self.spp if spp is None else spp, width, height,
-                            (0, 0, width, height), (0, 0, width, height), self.film_scale, r2c, c2w,
-                            self.fov, self.eye, self.focus, self.up, self.filename)
+                            crop, sample_bounds(crop, self.filter_radius), self.film_scale, r2c, c2w,
+                            self.fov, self.eye, self.focus, self.up, self.filename, self.filter_radius,
+                            self.max_sample_luminance)
+
+    def with_filter(self, radius, max_sample_luminance=None):
+        """Same film with another Box filter radius (and optionally another MaxLum)."""
+        radius = (float(radius[0]), float(radius[1]))
+        return replace(self, filter_radius=radius, sample_bounds=sample_bounds(self.cropped_bounds, radius),
+                       max_sample_luminance=self.max_sample_luminance if max_sample_luminance is None else float(max_sample_luminance))
+
+
+def sample_bounds(cropped_bounds, radius):
+    """Film::getSampleBounds (Object/Film.cpp:79-85) in float32, as the reference computes it."""
+    f = np.float32
+    x0 = np.floor(f(cropped_bounds[0]) + f(0.5) - f(radius[0]))
+    y0 = np.floor(f(cropped_bounds[1]) + f(0.5) - f(radius[1]))
+    x1 = np.ceil(f(cropped_bounds[2]) - f(0.5) + f(radius[0]))
+    y1 = np.ceil(f(cropped_bounds[3]) - f(0.5) + f(radius[1]))
+    return (int(min(x0, x1)), int(min(y0, y1)), int(max(x0, x1)), int(max(y0, y1)))
 
 
 def camera_matrices(fov, eye, focus, up, width, height):
@@ -179,7 +199,8 @@ class FlatScene:
         if cfg is not None:
             extra = dict(cfg_ints=np.array([cfg.integrator, cfg.max_depth, cfg.spp, cfg.width, cfg.height,
                                             *cfg.cropped_bounds, *cfg.sample_bounds], np.int32),
-                         cfg_floats=np.array([cfg.film_scale, cfg.fov, *cfg.eye, *cfg.focus, *cfg.up], np.float32),
+                         cfg_floats=np.array([cfg.film_scale, cfg.fov, *cfg.eye, *cfg.focus, *cfg.up, *cfg.filter_radius,
+                                              cfg.max_sample_luminance], np.float32),
                          raster_to_camera=cfg.raster_to_camera, camera_to_world=cfg.camera_to_world,
                          filename=np.array(cfg.filename))
         np.savez_compressed(path, nodes=self.nodes, leaf_idx=self.leaf_idx, bounds=self.bounds, tri_p=self.tri_p,
@@ -204,6 +225,8 @@ class FlatScene:
             cfg = RenderConfig(ci[0], ci[1], ci[2], ci[3], ci[4], tuple(ci[5:9]), tuple(ci[9:13]), cf[0],
                                z["raster_to_camera"].astype(np.float32), z["camera_to_world"].astype(np.float32),
                                cf[1], tuple(cf[2:5]), tuple(cf[5:8]), tuple(cf[8:11]), str(z["filename"]))
+            if len(cf) >= 14:   # files written before the filter parameters were stored hold the defaults
+                cfg = replace(cfg, filter_radius=(cf[11], cf[12]), max_sample_luminance=cf[13])
         tri_n = z["tri_n"] if z["tri_n"].shape[0] else None
         spheres = None
         if "spheres" in z.files and z["spheres"].size:
@@ -244,7 +267,7 @@ def _from_handle(h, with_config):
         cfg = RenderConfig(c.integrator, c.max_depth, c.spp, c.width, c.height, tuple(c.cropped_bounds),
                            tuple(c.sample_bounds), c.film_scale, np.array(list(c.raster_to_camera), np.float32),
                            np.array(list(c.camera_to_world), np.float32), c.fov, tuple(c.eye), tuple(c.focus),
-                           tuple(c.up), c.filename.decode())
+                           tuple(c.up), c.filename.decode(), tuple(c.filter_radius), float(c.max_sample_luminance))
     ts = RtHostTreeStats()
     _check(lib.rt_host_tree_stats_get(h, C.byref(ts)))
     spheres = None

@@ -39,6 +39,7 @@ def lib():
         l.oracle_create.restype = C.c_void_p
         l.oracle_destroy.argtypes = [C.c_void_p]
         l.oracle_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        l.oracle_set_film.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_float]
         l.oracle_trace_closest.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 7
         l.oracle_trace_any.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 5
         l.oracle_surface.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
@@ -76,6 +77,10 @@ class Oracle:
         r2c = np.ascontiguousarray(cfg.raster_to_camera, np.float32)
         c2w = np.ascontiguousarray(cfg.camera_to_world, np.float32)
         rc = self._l.oracle_set_camera(self._h, r2c.ctypes.data, c2w.ctypes.data, cfg.width, cfg.height, sb.ctypes.data)
+        assert rc == 0
+        cb = np.array(cfg.cropped_bounds, np.int32)
+        rc = self._l.oracle_set_film(self._h, C.c_float(cfg.filter_radius[0]), C.c_float(cfg.filter_radius[1]), cb.ctypes.data,
+                                     C.c_float(cfg.max_sample_luminance))
         assert rc == 0
         self.config = cfg
 

@@ -302,3 +302,50 @@ def test_scene_in_hbm_with_mixed_materials(gpu_ctx, path_scene):
     wrgb_g, ww_g = gpu_ctx.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=5, spp=2)
     assert np.array_equal(ww_g, ww_c)
     assert np.abs(_mean(wrgb_g, ww_g) - _mean(wrgb_c, ww_c)).max() <= 1e-4
+
+
+def test_film_window_wide_filter_and_clamp(gpu_ctx, path_scene, sphere_scene):
+    """rt_set_film: cropped pixel bounds, a Box filter wider than a pixel and "MaxLum" (Object/Film.h:111-155,
+    Film.cpp:17-37, 79-96) against the oracle, both integrators. With a wide filter most of a pixel's sum arrives from
+    neighbouring pixels' samples, in an order that differs between the two sides: weights must be equal, sums agree to
+    float rounding."""
+    from dataclasses import replace
+    import oracle_lib
+    base = path_scene.config.with_resolution(80, 56, spp=8)
+    cfg = replace(base, cropped_bounds=(7, 5, 71, 50)).with_filter((1.0, 1.5), max_sample_luminance=1.5)
+    for scene in (path_scene, sphere_scene):
+        orc = Oracle(scene, cfg)
+        gpu_ctx.upload_scene(scene)
+        gpu_ctx.set_camera(cfg)
+        for integrator in (RT_INTEGRATOR_WHITTED, RT_INTEGRATOR_PATH):
+            grgb, gw = gpu_ctx.render(integrator=integrator, rng_mode=RT_RNG_COUNTER, seed=9, max_depth=5, spp_per_pass=3)
+            oracle_lib.set_trig_mode(True)
+            try:
+                crgb, cw, _ = orc.render(integrator=integrator, rng_mode=RT_RNG_COUNTER, seed=9, max_depth=5)
+            finally:
+                oracle_lib.set_trig_mode(False)
+            assert np.array_equal(gw, cw)
+            assert not gw[:5].any() and not gw[:, :7].any() and not gw[50:].any() and not gw[:, 71:].any()
+            assert gw[5:50, 7:71].min() > 0
+            np.testing.assert_allclose(grgb, crgb, rtol=2e-5, atol=1e-6)
+            lum = _mean(grgb, gw) @ np.array([0.212671, 0.715160, 0.072169], np.float32)
+            assert lum.max() <= 1.5 * (1 + 1e-5)
+    # full window: the sample bounds then start at negative film coordinates
+    full = base.with_filter((1.0, 1.5))
+    assert full.sample_bounds == (-1, -1, 81, 57)
+    gpu_ctx.set_camera(full)
+    grgb, gw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=4)
+    oracle_lib.set_trig_mode(True)
+    try:
+        crgb, cw, _ = Oracle(sphere_scene, full).render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=4)
+    finally:
+        oracle_lib.set_trig_mode(False)
+    assert np.array_equal(gw, cw) and gw.min() > 0
+    np.testing.assert_allclose(grgb, crgb, rtol=2e-5, atol=1e-6)
+    # argument checks
+    lib, h = gpu_ctx._lib, gpu_ctx._h
+    cb = np.array([0, 0, 81, 56], np.int32)
+    assert lib.rt_set_film(h, 0.5, 0.5, cb.ctypes.data, float("inf")) != 0      # outside the film
+    cb = np.array([0, 0, 80, 56], np.int32)
+    assert lib.rt_set_film(h, 0.0, 0.5, cb.ctypes.data, float("inf")) != 0      # no radius
+    assert lib.rt_set_film(h, 0.5, 0.5, cb.ctypes.data, float("inf")) == 0

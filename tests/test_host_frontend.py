@@ -158,3 +158,27 @@ def test_loader_handles_sphere_entities(sphere_scene):
     # every leaf that references a sphere lies inside the sphere's box, and the sphere is referenced at all
     refs = set(int(v) for v in s.leaf_idx) | set(int(n[0]) for n in s.nodes if (n[1] & 3) == 3 and (n[1] >> 2) == 1)
     assert {38, 39} <= refs
+
+
+def test_loader_reads_film_window_filter_and_clamp(tmp_path):
+    """Film "CropMin"/"CropMax", Filter "Radius" and "MaxLum" (Object/Film.cpp:17-37) and the sample bounds that follow
+    from them (Film::getSampleBounds, Film.cpp:79-85), on a scene written here (one quad, own OBJ file)."""
+    import json
+    from raytracing_amd.scene import sample_bounds
+    (tmp_path / "quad.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    scene = {"Renderer": {"Type": "Whitted", "Depth": 3, "Sampler": {"Type": "Random", "SPP": 2},
+                          "Camera": {"Type": "Perspective", "Fov": 40, "Eye": [0.5, 0.5, -3], "Focus": [0.5, 0.5, 0], "WorldUp": [0, 1, 0],
+                                     "Film": {"Type": "Film", "Resolution": [100, 60], "CropMin": [0.105, 0.2], "CropMax": [0.9, 0.75],
+                                              "MaxLum": 2.5, "Filename": "q.png", "Filter": {"Type": "Box", "Radius": [1.0, 1.75]}}}},
+             "Entity": [{"Type": "MeshEntity", "Filename": "quad.obj", "Shape": {"Type": "Triangle"},
+                         "Material": {"Type": "Lambertian", "R": [0.5, 0.5, 0.5]}}]}
+    (tmp_path / "s.json").write_text(json.dumps(scene))
+    cfg = load_scene_json(str(tmp_path / "s.json")).config
+    assert cfg.cropped_bounds == (11, 12, 90, 45)          # ceil(100 * 0.105), ceil(60 * 0.2), ceil(100 * 0.9), ceil(60 * 0.75)
+    assert cfg.filter_radius == (1.0, 1.75) and cfg.max_sample_luminance == 2.5
+    assert cfg.sample_bounds == (10, 10, 91, 47)            # floor(11.5 - 1), floor(12.5 - 1.75), ceil(89.5 + 1), ceil(44.5 + 1.75)
+    assert cfg.sample_bounds == sample_bounds(cfg.cropped_bounds, cfg.filter_radius)
+    # defaults, and the filter carried through a change of resolution
+    wide = cfg.with_resolution(40, 30)
+    assert wide.filter_radius == (1.0, 1.75) and wide.cropped_bounds == (0, 0, 40, 30) and wide.sample_bounds == (-1, -2, 41, 32)
+    assert FlatScene.load_npz(os.path.join(GOLDEN, "cornellBox_path.npz")).config.filter_radius == (0.5, 0.5)

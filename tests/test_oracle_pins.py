@@ -247,3 +247,36 @@ def test_sphere_light_sampling_is_consistent(sphere_scene):
     assert light_px.sum() > 20 and mirror_px.sum() > 20
     assert img[light_px].mean() > 1.5          # Le = (2, 2, 2) seen directly
     assert 0.01 < img[mirror_px].mean() < 1.5
+
+
+def test_film_window_filter_radius_and_clamp(path_scene):
+    """FilmTile::addSample beyond the shipped scenes' 0.5 box (Object/Film.h:111-155, Film.cpp:79-96): a wider Box filter
+    spreads every sample over the pixels within its radius (weight 1 each), only the cropped pixel bounds receive
+    samples, "MaxLum" scales brighter samples down. No fixture of the reference covers these parameters (its scenes all
+    use radius 0.5, the full window and no clamp): parity unpinned, checked through the properties the definition gives."""
+    from dataclasses import replace
+    from raytracing_amd._ctypes_defs import RT_INTEGRATOR_WHITTED, RT_RNG_COUNTER
+    base = path_scene.config.with_resolution(64, 48, spp=16)
+    crop = (6, 5, 57, 40)
+    cfg = replace(base, cropped_bounds=crop).with_filter((1.0, 1.5), max_sample_luminance=1.5)
+    assert cfg.sample_bounds == (5, 4, 58, 41)
+    rgb, w, st = Oracle(path_scene, cfg).render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_COUNTER, seed=2, max_depth=3)
+    inside = np.zeros((48, 64), bool)
+    inside[crop[1]:crop[3], crop[0]:crop[2]] = True
+    assert not w[~inside].any() and not rgb[~inside].any()
+    assert st["camera_samples"] == (58 - 5) * (41 - 4) * 16
+    # a pixel collects the samples of a 2 x 3 pixel box around its centre: (2 * 1.0) * (2 * 1.5) * spp on average
+    assert (w[inside] > 0).all() and abs(w[inside].mean() / (2.0 * 3.0 * 16) - 1) < 0.02
+    assert w.max() <= 3 * 4 * 16   # at most 3 x 4 pixel positions can reach one pixel
+    lum = (rgb / np.maximum(w, 1)[..., None]) @ np.array([0.212671, 0.715160, 0.072169], np.float32)
+    assert lum.max() <= 1.5 * (1 + 1e-5)
+    # without the clamp the luminaire (radiance 5, 4, 4) is brighter than that, so the clamp did act
+    rgb2, w2, _ = Oracle(path_scene, replace(cfg, max_sample_luminance=float("inf"))).render(
+        integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_COUNTER, seed=2, max_depth=3)
+    assert np.array_equal(w2, w)
+    lum2 = (rgb2 / np.maximum(w2, 1)[..., None]) @ np.array([0.212671, 0.715160, 0.072169], np.float32)
+    assert lum2.max() > 3.0
+    # radius 0.5 over the full window through the same entry points is the plain render
+    plain = Oracle(path_scene, base).render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_COUNTER, seed=2, max_depth=3)
+    again = Oracle(path_scene, base.with_filter((0.5, 0.5))).render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_COUNTER, seed=2, max_depth=3)
+    assert np.array_equal(plain[0], again[0]) and np.array_equal(plain[1], again[1])
