@@ -278,6 +278,8 @@ static void load_json_impl(const std::string &path, rt_host_scene &S) {
     S.has_cfg = true;
 
     // ---- Entities --------------------------------------------------------------------------------
+    static const float kDefaultUV[6] = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f};
+    bool anyUV = false;
     const JsonValue *ej = root.find("Entity");
     if (!ej || ej->kind != JsonValue::Array) throw std::runtime_error("there is no Entity in " + path);
     for (const JsonValue &e : ej->arr) {
@@ -319,6 +321,7 @@ static void load_json_impl(const std::string &path, rt_host_scene &S) {
             store_m4(o2w.inv, sp.world_to_object);   // inverse(Transform) swaps the pair (Utils/Transform.h)
             S.spheres.push_back(sp);
             for (int k = 0; k < 9; ++k) { S.tri_p.push_back(0.f); S.tri_n.push_back(0.f); }
+            for (float v : kDefaultUV) S.tri_uv.push_back(v);
             S.tri_has_n.push_back(0);
             S.material_id.push_back(matId);
             if (lj) {
@@ -332,7 +335,10 @@ static void load_json_impl(const std::string &path, rt_host_scene &S) {
         }
         ImportedMesh mesh;
         import_obj(dir + ep.getString("Filename"), mesh);
-        if (!mesh.uv.empty()) throw std::runtime_error("OBJ files with texture coordinates are not supported by this front-end yet");
+        // TriangleMesh keeps mTextureCoords[0] when the file has them (TriangleShape.cpp:28-37, 97-110); a triangle of a
+        // mesh without them gets (0,0), (1,0), (1,1) (:396-401)
+        const bool meshHasUV = !mesh.uv.empty();
+        anyUV = anyUV || meshHasUV;
         // TriangleMesh: bake objectToWorld into positions (w=1) and normals (w=0)
         // (reference src/core/Shape/TriangleShape.cpp:100-111)
         std::vector<V3> wp(mesh.position.size()), wn(mesh.position.size());
@@ -349,6 +355,11 @@ static void load_json_impl(const std::string &path, rt_host_scene &S) {
                 V3 n = wn[mesh.indices[t + k]];
                 S.tri_n.push_back(n.x); S.tri_n.push_back(n.y); S.tri_n.push_back(n.z);
             }
+            for (int k = 0; k < 3; ++k) {
+                const size_t vi = (size_t)mesh.indices[t + k];
+                S.tri_uv.push_back(meshHasUV ? mesh.uv[2 * vi] : kDefaultUV[2 * k]);
+                S.tri_uv.push_back(meshHasUV ? mesh.uv[2 * vi + 1] : kDefaultUV[2 * k + 1]);
+            }
             S.tri_has_n.push_back(1);
             S.material_id.push_back(matId);
             if (lj) {
@@ -361,6 +372,7 @@ static void load_json_impl(const std::string &path, rt_host_scene &S) {
         }
     }
     if (S.material_id.empty()) throw std::runtime_error("scene has no primitives");
+    if (!anyUV) S.tri_uv.clear();   // all defaults: the consumer's own default is the same
     S.finish();
 }
 

@@ -143,6 +143,7 @@ class FlatScene:
     config: Optional[RenderConfig] = None
     tree_stats: Optional[dict] = None
     spheres: Optional[np.ndarray] = None   # structured (_SPHERE_DTYPE); primitives listed here are spheres
+    tri_uv: Optional[np.ndarray] = None    # (n_prims, 6) float32 or None: texture coordinates of the three corners
 
     @property
     def shape_type(self):
@@ -180,6 +181,8 @@ class FlatScene:
         d.tri_p = ptr(self.tri_p.astype(np.float32, copy=False), C.c_float)
         if self.tri_n is not None:
             d.tri_n = ptr(self.tri_n.astype(np.float32, copy=False), C.c_float)
+        if self.tri_uv is not None:
+            d.tri_uv = ptr(self.tri_uv.astype(np.float32, copy=False), C.c_float)
         d.material_id = ptr(self.material_id.astype(np.int32, copy=False), C.c_int32)
         d.light_id = ptr(self.light_id.astype(np.int32, copy=False), C.c_int32)
         d.n_materials = int(self.materials.shape[0])
@@ -209,7 +212,8 @@ class FlatScene:
                             mat_type=self.materials["type"], mat_rgb=self.materials["rgb"], mat_eta=self.materials["eta"],
                             light_prim=self.lights["prim_id"], light_emit=self.lights["emit"],
                             light_two_sided=self.lights["two_sided"],
-                            spheres=(self.spheres if self.spheres is not None else np.zeros(0, _SPHERE_DTYPE)).view(np.uint8), **extra)
+                            spheres=(self.spheres if self.spheres is not None else np.zeros(0, _SPHERE_DTYPE)).view(np.uint8),
+                            tri_uv=self.tri_uv if self.tri_uv is not None else np.zeros((0, 6), np.float32), **extra)
 
     @staticmethod
     def load_npz(path):
@@ -231,8 +235,9 @@ class FlatScene:
         spheres = None
         if "spheres" in z.files and z["spheres"].size:
             spheres = np.ascontiguousarray(z["spheres"]).view(_SPHERE_DTYPE).copy()
+        tri_uv = z["tri_uv"] if "tri_uv" in z.files and z["tri_uv"].shape[0] else None
         return FlatScene(z["nodes"], z["leaf_idx"], z["bounds"], z["tri_p"], tri_n, z["material_id"], z["light_id"],
-                         mats, lights, cfg, None, spheres)
+                         mats, lights, cfg, None, spheres, tri_uv)
 
 
 def _from_handle(h, with_config):
@@ -250,6 +255,7 @@ def _from_handle(h, with_config):
     bounds = np.array(list(d.bounds), np.float32)
     tri_p = arr(d.tri_p, 9 * n, np.float32).reshape(-1, 9)
     tri_n = arr(d.tri_n, 9 * n, np.float32).reshape(-1, 9) if d.tri_n else None
+    tri_uv = arr(d.tri_uv, 6 * n, np.float32).reshape(-1, 6) if d.tri_uv else None
     material_id = arr(d.material_id, n, np.int32)
     light_id = arr(d.light_id, n, np.int32)
     mats = np.zeros(d.n_materials, _MAT_DTYPE)
@@ -276,7 +282,7 @@ def _from_handle(h, with_config):
         for i in range(d.n_spheres):
             sp = d.spheres[i]
             spheres[i] = (sp.prim_id, sp.radius, tuple(sp.object_to_world), tuple(sp.world_to_object))
-    return FlatScene(nodes, leaf_idx, bounds, tri_p, tri_n, material_id, light_id, mats, lights, cfg, ts.as_dict(), spheres)
+    return FlatScene(nodes, leaf_idx, bounds, tri_p, tri_n, material_id, light_id, mats, lights, cfg, ts.as_dict(), spheres, tri_uv)
 
 
 def load_scene_json(path) -> FlatScene:
@@ -290,7 +296,7 @@ def load_scene_json(path) -> FlatScene:
         lib.rt_host_free(h)
 
 
-def build_scene(tri_p, material_id, materials, tri_n=None, light_id=None, lights=None, config=None) -> FlatScene:
+def build_scene(tri_p, material_id, materials, tri_n=None, light_id=None, lights=None, config=None, tri_uv=None) -> FlatScene:
     """Builds the KD-tree over caller-supplied world-space triangles (synthetic scenes)."""
     lib = host_lib()
     tri_p = np.ascontiguousarray(tri_p, np.float32).reshape(-1, 9)
@@ -301,7 +307,8 @@ def build_scene(tri_p, material_id, materials, tri_n=None, light_id=None, lights
     lid = None if light_id is None else np.ascontiguousarray(light_id, np.int32)
     lts = np.zeros(0, _LIGHT_DTYPE) if lights is None else np.ascontiguousarray(lights, _LIGHT_DTYPE)
     h = C.c_void_p()
-    _check(lib.rt_host_build(n, tri_p.ctypes.data, None if tn is None else tn.ctypes.data, None,
+    tuv = None if tri_uv is None else np.ascontiguousarray(tri_uv, np.float32).reshape(-1, 6)
+    _check(lib.rt_host_build(n, tri_p.ctypes.data, None if tn is None else tn.ctypes.data, None if tuv is None else tuv.ctypes.data,
                              material_id.ctypes.data, None if lid is None else lid.ctypes.data,
                              mats.shape[0], mats.ctypes.data, lts.shape[0], lts.ctypes.data if lts.shape[0] else None,
                              C.byref(h)))

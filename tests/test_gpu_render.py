@@ -349,3 +349,32 @@ def test_film_window_wide_filter_and_clamp(gpu_ctx, path_scene, sphere_scene):
     cb = np.array([0, 0, 80, 56], np.int32)
     assert lib.rt_set_film(h, 0.0, 0.5, cb.ctypes.data, float("inf")) != 0      # no radius
     assert lib.rt_set_film(h, 0.5, 0.5, cb.ctypes.data, float("inf")) == 0
+
+
+def test_texture_coordinates_set_the_shading_frame(gpu_ctx, path_scene):
+    """Per-corner texture coordinates decide dpdu, hence the frame BSDF samples are drawn in (TriangleShape.cpp:389-412,
+    Render/BSDF.h:30-31): same scene with seeded random coordinates, both integrators against the oracle."""
+    from dataclasses import replace
+    import oracle_lib
+    rs = np.random.RandomState(11)
+    uv = rs.uniform(0, 1, (path_scene.n_prims, 6)).astype(np.float32)
+    uv[3] = [0.5, 0.5, 0.5, 0.5, 0.5, 0.5]   # degenerate coordinates fall back to coordinateSystem(ng) (:414-421)
+    scene = replace(path_scene, tri_uv=uv)
+    cfg = path_scene.config.with_resolution(96, 96, spp=8)
+    orc = Oracle(scene, cfg)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cfg)
+    grgb, gw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=4)
+    oracle_lib.set_trig_mode(True)
+    try:
+        crgb, cw, _ = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=4)
+    finally:
+        oracle_lib.set_trig_mode(False)
+    assert np.array_equal(gw, cw)
+    neq = (grgb != crgb).any(axis=2)
+    assert np.count_nonzero(neq) <= 4 and np.abs(grgb - crgb).max() <= 2e-6 * np.abs(crgb).max()
+    # and the coordinates matter: the default corners give other sample directions
+    gpu_ctx.upload_scene(path_scene)
+    gpu_ctx.set_camera(cfg)
+    prgb, _ = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=4)
+    assert (prgb != grgb).any(axis=2).mean() > 0.3

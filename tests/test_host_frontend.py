@@ -182,3 +182,36 @@ def test_loader_reads_film_window_filter_and_clamp(tmp_path):
     wide = cfg.with_resolution(40, 30)
     assert wide.filter_radius == (1.0, 1.75) and wide.cropped_bounds == (0, 0, 40, 30) and wide.sample_bounds == (-1, -2, 41, 32)
     assert FlatScene.load_npz(os.path.join(GOLDEN, "cornellBox_path.npz")).config.filter_radius == (0.5, 0.5)
+
+
+def test_loader_keeps_texture_coordinates(tmp_path):
+    """OBJ "vt" records: one (u, 1 - v) pair per face corner (aiProcess_FlipUVs, TriangleShape.cpp:34-37, 77-78), which
+    ATriangleShape::hit turns into dpdu (TriangleShape.cpp:389-412). A mesh without them gets the reference's default
+    corners (0,0), (1,0), (1,1) (:396-401)."""
+    import json
+    from oracle_lib import Oracle
+    (tmp_path / "a.obj").write_text("v 0 0 0\nv 2 0 0\nv 2 2 0\nv 0 2 0\nvt 0.25 0.125\nvt 0.75 0.125\nvt 0.75 0.5\nvt 0.25 0.5\n"
+                                    "f 1/1 2/2 3/3 4/4\n")
+    (tmp_path / "b.obj").write_text("v 0 0 1\nv 2 0 1\nv 2 2 1\nf 1 2 3\n")
+    ent = lambda f: {"Type": "MeshEntity", "Filename": f, "Shape": {"Type": "Triangle"}, "Material": {"Type": "Lambertian", "R": [0.5, 0.5, 0.5]}}
+    scene = {"Renderer": {"Type": "Path", "Depth": 2, "Sampler": {"Type": "Random", "SPP": 1},
+                          "Camera": {"Type": "Perspective", "Fov": 40, "Eye": [1, 1, -5], "Focus": [1, 1, 0], "WorldUp": [0, 1, 0],
+                                     "Film": {"Type": "Film", "Resolution": [16, 16], "Filter": {"Type": "Box"}}}},
+             "Entity": [ent("a.obj"), ent("b.obj")]}
+    (tmp_path / "s.json").write_text(json.dumps(scene))
+    s = load_scene_json(str(tmp_path / "s.json"))
+    assert s.n_prims == 3 and s.tri_uv.shape == (3, 6)
+    assert np.array_equal(s.tri_uv[0], np.float32([0.25, 0.875, 0.75, 0.875, 0.75, 0.5]))
+    assert np.array_equal(s.tri_uv[1], np.float32([0.25, 0.875, 0.75, 0.5, 0.25, 0.5]))
+    assert np.array_equal(s.tri_uv[2], np.float32([0, 0, 1, 0, 1, 1]))
+    # dpdu of the quad's first triangle: u grows along +x, 0.5 per 2 units -> dpdu = (4, 0, 0); default corners on the
+    # lone triangle: dpdu = p1 - p0 = (2, 0, 0)
+    orc = Oracle(s)
+    b = np.float32([0.3, 0.3, 0.4])
+    d = np.float32([0, 0, 1])
+    np.testing.assert_allclose(orc.surface(0, b, d)[3], [4, 0, 0], atol=1e-6)
+    np.testing.assert_allclose(orc.surface(2, b, d)[3], [2, 0, 0], atol=1e-6)
+    # a scene without any "vt" keeps no table at all
+    scene["Entity"] = [ent("b.obj")]
+    (tmp_path / "t.json").write_text(json.dumps(scene))
+    assert load_scene_json(str(tmp_path / "t.json")).tri_uv is None
