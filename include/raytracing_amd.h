@@ -103,7 +103,10 @@ enum { RT_INTEGRATOR_PATH = 0, RT_INTEGRATOR_WHITTED = 1 };
 /* RNG layout. REFERENCE_TILE_STREAM reproduces the reference's sampler exactly: one PCG32 stream per
  * 16x16 tile seeded with the tile index, consumed serially pixel by pixel, sample by sample
  * (Render/Render.cpp:32-92, Render/Sampler.cpp:174-179). COUNTER gives every camera sample its own
- * PCG32 stream (sequence = (pixel index * spp_total + sample index) ^ seed scrambling, see rt_render). */
+ * PCG32 stream (sequence = (pixel index * spp_total + sample index) ^ seed scrambling, see rt_render).
+ * The tile stream is serial inside a tile and cannot be cut by sample index (spp_begin = 0, spp_end = spp_total); for the
+ * Path integrator it runs one tile per wavefront and is meant for reproducing the CPU renderer's image, COUNTER is the
+ * wavefront path tracer. */
 enum { RT_RNG_COUNTER = 0, RT_RNG_REFERENCE_TILE_STREAM = 1 };
 
 typedef struct rt_render_params {

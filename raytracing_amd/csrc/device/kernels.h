@@ -924,6 +924,178 @@ RT_DEV f3 whitted_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Path integrator on the reference's random stream (Render/Render.cpp:32-92, 348-449)
+// ---------------------------------------------------------------------------------------------------
+// PathRenderer::Li for one camera ray, start to finish in one lane, drawing from `rng` in the reference's order (light
+// choice, light sample, scattering sample, BSDF sample, Russian roulette). The arithmetic is that of k_shade / k_shadow
+// / k_probe; only here the rays of a path are traced where they arise, because the next sample's random numbers are
+// the ones that follow this path's last draw.
+template <bool LDS_SCENE, bool STATS, bool SPH>
+RT_DEV f3 path_li(const DevScene &sc, const SceneTables &tb, uint32_t *stk, f3 ro, f3 rdir, Pcg &rng, int maxDepth, float rrThreshold,
+                  TravCounters &cn, uint32_t &nClosest, uint32_t &nAny) {
+    f3 L = mk3(0.f, 0.f, 0.f), beta = mk3(1.f, 1.f, 1.f);
+    float etaScale = 1.f;
+    bool specularBounce = false;
+    for (int bounce = 0;; ++bounce) {
+        RayCtx r;
+        ray_setup(r, ro, rdir);
+        HitRec h;
+        ++nClosest;
+        const bool hit = kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, r, RT_INF, h, cn);
+        if (!hit) break;
+        Surf sf;
+        surface_at<SPH>(sc, h.prim, h.b0, h.b1, h.b2, ro, rdir, sf);
+        if ((bounce == 0 || specularBounce) && sf.light >= 0) L = L + beta * light_L(sc.lights[sf.light], sf.n, -rdir);
+        if (bounce >= maxDepth) break;
+        DBsdf bs;
+        bsdf_init<MATSET_ANY>(bs, sf, sc.mats[sf.mat]);
+        const f3 isectWo = normalize3(-rdir);
+        if (bsdf_num(bs, BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.nLights > 0) {
+            // uniformSampleOneLight -> estimateDirect (Render/Render.cpp:189-312)
+            float selPdf;
+            const int li = sample_light(sc, pcg_float(rng), selPdf);
+            if (selPdf != 0) {
+                const float ul0 = pcg_float(rng), ul1 = pcg_float(rng);
+                const float us0 = pcg_float(rng), us1 = pcg_float(rng);
+                const DevLight lt = sc.lights[li];
+                const int flags = BSDF_ALL & ~BSDF_SPECULAR;
+                f3 Ld = mk3(0.f, 0.f, 0.f);
+                f3 wi, pShape;
+                float lightPdf = 0, scatteringPdf = 0;
+                const f3 Li = light_sample_Li<SPH>(sc, lt, sf.p, ul0, ul1, wi, lightPdf, pShape);
+                if (lightPdf > 0 && !black3(Li)) {
+                    const f3 f = bsdf_f(bs, isectWo, wi, flags) * absdot3(wi, sf.n);
+                    scatteringPdf = bsdf_pdf(bs, isectWo, wi, flags);
+                    if (!black3(f)) {
+                        const float weight = power_heuristic(lightPdf, scatteringPdf);
+                        const f3 A = f * Li * weight / lightPdf;
+                        RayCtx sr;
+                        ray_setup(sr, sf.p, normalize3(pShape - sf.p));
+                        HitRec sh;
+                        ++nAny;
+                        if (!kd_trace<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, sr, 1 - RT_SHADOW_EPS, sh, cn))
+                            Ld = Ld + A;
+                    }
+                }
+                {
+                    f3 wi2 = mk3(0.f, 0.f, 0.f);
+                    float pdfB = scatteringPdf, weightB = 1;
+                    int sampledType = 0;
+                    f3 f2 = bsdf_sample(bs, isectWo, wi2, us0, us1, pdfB, sampledType, flags);
+                    f2 = f2 * absdot3(wi2, sf.n);
+                    if (!black3(f2) && pdfB > 0) {
+                        bool go = true;
+                        if ((sampledType & BSDF_SPECULAR) == 0) {
+                            const float lp = light_pdf_Li<SPH>(sc, lt, sf.p, wi2);
+                            if (lp == 0) go = false;
+                            else weightB = power_heuristic(pdfB, lp);
+                        }
+                        if (go) {
+                            RayCtx pr;
+                            ray_setup(pr, sf.p, normalize3(wi2));
+                            HitRec ph;
+                            ++nClosest;
+                            f3 Li2 = mk3(0.f, 0.f, 0.f);
+                            if (kd_trace<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, stk, threadIdx.x, pr, RT_INF, ph, cn)) {
+                                Surf ps;
+                                surface_at<SPH>(sc, ph.prim, ph.b0, ph.b1, ph.b2, sf.p, pr.d, ps);
+                                if (ps.light == li) Li2 = light_L(sc.lights[li], ps.n, -wi2);
+                            }
+                            if (!black3(Li2)) Ld = Ld + f2 * Li2 * mk3(1.f, 1.f, 1.f) * weightB / pdfB;
+                        }
+                    }
+                }
+                L = L + beta * (Ld / selPdf);
+            }
+        }
+        // next direction
+        const f3 wo = -rdir;
+        f3 wi = mk3(0.f, 0.f, 0.f);
+        float pdf = 0;
+        int flags = 0;
+        const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+        const f3 f = bsdf_sample(bs, wo, wi, u0, u1, pdf, flags, BSDF_ALL);
+        if (black3(f) || pdf == 0.f) break;
+        beta = beta * (f * absdot3(wi, sf.n) / pdf);
+        specularBounce = (flags & BSDF_SPECULAR) != 0;
+        if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+            const float eta = bs.eta;
+            etaScale *= (dot3(wo, sf.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+        }
+        ro = sf.p;
+        rdir = normalize3(wi);
+        const f3 rrBeta = beta * etaScale;
+        const float mx = gmax(gmax(rrBeta.x, rrBeta.y), rrBeta.z);
+        if (mx < rrThreshold && bounce > 3) {
+            const float q = gmax(.05f, 1 - mx);
+            if (pcg_float(rng) < q) break;
+            beta = beta / (1 - q);
+        }
+    }
+    return L;
+}
+
+// The reference's render loop for the Path integrator with its own random stream: tile t draws from PCG32 sequence t,
+// pixel after pixel, sample after sample (Render/Render.cpp:32-92). The stream is serial inside a tile, so a tile is
+// one lane's work; each tile gets a wave to itself (lane 0), which keeps 1024 SIMDs busy with thousands of tiles and
+// costs no divergence. This mode exists to reproduce the CPU renderer's image exactly; RT_RNG_COUNTER is the fast one.
+template <bool LDS_SCENE, bool STATS, bool SPH>
+__global__ __launch_bounds__(RT_BLOCK) void k_path_tile_stream(DevScene sc, CameraDev cam, int spp, int maxDepth, float rrThreshold, uint32_t nTiles,
+                                                               uint32_t ntx, float *rgbSum, float *weightSum, float *spillRgb, float *spillW,
+                                                               unsigned long long *stats) {
+    extern __shared__ uint4 smem[];
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
+    TravCounters cn = {0, 0, 0, 0, 0};
+    uint32_t nc = 0, na = 0, ns = 0;
+    const uint32_t wavesPerBlock = RT_BLOCK / 64;
+    const uint32_t t = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0 && t < nTiles) {
+        const int tx = (int)(t % ntx), ty = (int)(t / ntx);
+        const int x0 = cam.sb[0] + tx * 16, x1 = min(x0 + 16, cam.sb[2]);
+        const int y0 = cam.sb[1] + ty * 16, y1 = min(y0 + 16, cam.sb[3]);
+        Pcg rng;
+        pcg_set_sequence(rng, (uint64_t)t);
+        for (int py = y0; py < y1; ++py)
+            for (int px = x0; px < x1; ++px) {
+                const bool onFilm = px >= cam.cb[0] && px < cam.cb[2] && py >= cam.cb[1] && py < cam.cb[3];
+                const size_t g = onFilm ? (size_t)py * cam.width + px : 0;
+                f3 acc = mk3(0.f, 0.f, 0.f);
+                float w = 0.f;
+                if (onFilm) {
+                    acc = mk3(rgbSum[3 * g], rgbSum[3 * g + 1], rgbSum[3 * g + 2]);
+                    w = weightSum[g];
+                }
+                for (int s = 0; s < spp; ++s) {
+                    const float u0 = pcg_float(rng), u1 = pcg_float(rng);
+                    const float pfx = (float)px + u0, pfy = (float)py + u1;
+                    f3 o, d;
+                    camera_ray(cam, pfx, pfy, o, d);
+                    f3 L = path_li<LDS_SCENE, STATS, SPH>(sc, tb, stk, o, d, rng, maxDepth, rrThreshold, cn, nc, na);
+                    L = film_clamp(cam, sanitize_L(L));
+                    ++ns;
+                    int fx0, fy0, fx1, fy1;
+                    if (film_footprint(cam, pfx, pfy, px, py, fx0, fy0, fx1, fy1)) {
+                        acc = acc + L;
+                        w += 1.0f;
+                    } else {
+                        film_spill(cam, spillRgb, spillW, px, py, fx0, fy0, fx1, fy1, L, acc, w);
+                    }
+                }
+                if (onFilm) {
+                    rgbSum[3 * g] = acc.x; rgbSum[3 * g + 1] = acc.y; rgbSum[3 * g + 2] = acc.z;
+                    weightSum[g] = w;
+                }
+            }
+    }
+    if (STATS) flush_counters(stats, cn, nc + na);
+    if (nc) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)nc);
+    if (na) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)na);
+    if (ns) atomicAdd(&stats[ST_CAMERA_SAMPLES], (unsigned long long)ns);
+}
+
 // Reference tile stream, step 1: one lane per 16x16 tile walks the tile's samples in the reference's
 // order (Render/Render.cpp:32-92) consuming random numbers exactly as the full evaluation would, and
 // records the PCG32 state at the first sample of every pixel.

@@ -295,8 +295,6 @@ int check_render_args(rt_context *c, const rt_render_params *p) {
     if (p->max_depth < 0 || p->max_depth > 1024) return fail(c, RT_ERR_INVALID_ARG, "bad max_depth");
     if (p->rng_mode != RT_RNG_COUNTER && p->rng_mode != RT_RNG_REFERENCE_TILE_STREAM) return fail(c, RT_ERR_INVALID_ARG, "unknown rng_mode");
     if (p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM) {
-        if (p->integrator == RT_INTEGRATOR_PATH)
-            return fail(c, RT_ERR_UNSUPPORTED, "the reference tile stream is serial per tile; the wavefront path tracer uses RT_RNG_COUNTER");
         if (p->spp_begin != 0 || p->spp_end != p->spp_total)
             return fail(c, RT_ERR_INVALID_ARG, "the reference tile stream cannot be split by sample index");
     }
@@ -406,6 +404,26 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     return RT_OK;
 }
 
+// Path integrator on the reference's per-tile random stream: one wave (lane 0) per 16x16 tile, see k_path_tile_stream.
+int render_path_tile_stream(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    const CameraDev &cam = c->cam;
+    const int sbW = cam.sb[2] - cam.sb[0], sbH = cam.sb[3] - cam.sb[1];
+    if (sbW <= 0 || sbH <= 0 || p->spp_total == 0) return RT_OK;
+    int rc;
+    if ((rc = ensure_spill(c))) return rc;
+    const uint32_t ntx = (uint32_t)(sbW + 15) / 16, nty = (uint32_t)(sbH + 15) / 16;
+    const uint32_t nTiles = ntx * nty;
+    const uint32_t wavesPerBlock = RT_BLOCK / 64;
+    auto k = RT_PICK(k_path_tile_stream, c, p->collect_stats != 0);
+    hipLaunchKernelGGL(k, dim3((nTiles + wavesPerBlock - 1) / wavesPerBlock), dim3(RT_BLOCK), trace_lds_bytes(c), c->stream, c->sc, cam, p->spp_total,
+                       p->max_depth, p->rr_threshold, nTiles, ntx, rgb, wsum, c->dSpillRgb, c->dSpillW, c->dStats);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_merge_spill, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, (size_t)cam.width * cam.height, rgb, wsum, c->dSpillRgb,
+                       c->dSpillW);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
 int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
     const CameraDev &cam = c->cam;
     const int sbW = cam.sb[2] - cam.sb[0], sbH = cam.sb[3] - cam.sb[1];
@@ -479,6 +497,11 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
                        c->dSpillW);
     HIPCHK(c, hipGetLastError());
     return RT_OK;
+}
+
+int render_dispatch(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    if (p->integrator == RT_INTEGRATOR_WHITTED) return render_whitted(c, p, rgb, wsum);
+    return p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM ? render_path_tile_stream(c, p, rgb, wsum) : render_path(c, p, rgb, wsum);
 }
 
 }  // namespace
@@ -829,7 +852,7 @@ int rt_render_dev(rt_context *c, const rt_render_params *p, float *rgb, float *w
     if (rc) return rc;
     if (!rgb || !wsum) return fail(c, RT_ERR_INVALID_ARG, "output buffers are NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    return p->integrator == RT_INTEGRATOR_PATH ? render_path(c, p, rgb, wsum) : render_whitted(c, p, rgb, wsum);
+    return render_dispatch(c, p, rgb, wsum);
 }
 
 int rt_render(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
@@ -845,7 +868,7 @@ int rt_render(rt_context *c, const rt_render_params *p, float *rgb, float *wsum)
     CK(hipMemcpy(dRgb, rgb, n * 12, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, wsum, n * 4, hipMemcpyHostToDevice));
     const auto t0 = std::chrono::steady_clock::now();
-    rc = p->integrator == RT_INTEGRATOR_PATH ? render_path(c, p, dRgb, dW) : render_whitted(c, p, dRgb, dW);
+    rc = render_dispatch(c, p, dRgb, dW);
     if (rc == RT_OK) {
         CK(hipStreamSynchronize(c->stream));
         c->renderMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -135,8 +135,8 @@ def test_path_full_config_against_reference_image(gpu_ctx, path_scene, reference
 def test_render_argument_errors(gpu_ctx, path_scene):
     from raytracing_amd.device import RtError
     gpu_ctx.upload_scene(path_scene)
-    with pytest.raises(RtError):
-        gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, spp=1)
+    with pytest.raises(RtError):   # the tile stream cannot be cut by sample index
+        gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, spp=4, spp_end=2)
     with pytest.raises(RtError):
         gpu_ctx.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, spp=4, spp_begin=1)
     with pytest.raises(RtError):
@@ -378,3 +378,62 @@ def test_texture_coordinates_set_the_shading_frame(gpu_ctx, path_scene):
     gpu_ctx.set_camera(cfg)
     prgb, _ = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=4)
     assert (prgb != grgb).any(axis=2).mean() > 0.3
+
+
+def test_path_on_the_reference_tile_stream(gpu_ctx, path_scene, sphere_scene):
+    """PathRenderer::Li fed by the reference's own sampler (one PCG32 stream per 16x16 tile, Render.cpp:32-92): the
+    render that reproduces the CPU renderer's image sample for sample. Against the oracle in the same mode:
+    (a) oracle with correctly rounded cos/sin -> bit-equal sums (but for border-rounded film positions);
+    (b) oracle on libm like the reference -> paths fork where the last bit of a cosine differs; because one stream
+        feeds a whole tile, the samples that follow a fork in a tile draw other numbers too, so the bound is statistical:
+        equal weights, image RMSE within the noise of the sample count."""
+    import copy
+    import oracle_lib
+    from raytracing_amd.scene import make_materials
+    mixed = copy.copy(path_scene)
+    mats = mixed.materials.copy()
+    mats[6] = make_materials([(2, (0.9, 0.9, 0.9), 1.5)])[0]    # short box: glass
+    mats[7] = make_materials([(1, (0.8, 0.8, 0.8), 1.0)])[0]    # tall box: mirror
+    mixed.materials = mats
+    for scene, res, spp in ((path_scene, (72, 56), 12), (mixed, (64, 64), 8), (sphere_scene, (48, 48), 8)):
+        cfg = scene.config.with_resolution(res[0], res[1], spp=spp)
+        orc = Oracle(scene, cfg)
+        gpu_ctx.upload_scene(scene)
+        gpu_ctx.set_camera(cfg)
+        gpu_ctx.reset_stats()
+        grgb, gw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_REFERENCE_TILE_STREAM)
+        gs = gpu_ctx.stats()
+        oracle_lib.set_trig_mode(True)
+        try:
+            crgb, cw, st = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_REFERENCE_TILE_STREAM)
+        finally:
+            oracle_lib.set_trig_mode(False)
+        assert np.array_equal(gw, cw)
+        assert gs["rays_closest"] == st["rays_closest"] and gs["rays_any"] == st["rays_any"]
+        neq = (grgb != crgb).any(axis=2)
+        assert np.count_nonzero(neq) <= 4, f"{np.count_nonzero(neq)} pixels differ, max {np.abs(grgb - crgb).max()}"
+        assert np.abs(grgb - crgb).max() <= 2e-6 * np.abs(crgb).max()
+    # (b) on the plain cornellBox, libm oracle
+    cfg = path_scene.config.with_resolution(72, 56, spp=12)
+    gpu_ctx.upload_scene(path_scene)
+    gpu_ctx.set_camera(cfg)
+    grgb, gw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_REFERENCE_TILE_STREAM)
+    crgb, cw, _ = Oracle(path_scene, cfg).render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_REFERENCE_TILE_STREAM)
+    assert np.array_equal(gw, cw)
+    g, c = _mean(grgb, gw), _mean(crgb, cw)
+    assert abs(g.mean() / c.mean() - 1) < 0.03
+
+
+def test_path_tile_stream_reproduces_the_published_image(gpu_ctx, path_scene, reference_png):
+    """BASELINE config 1 with the reference's own sampler on the GPU: cornellBox Path 800x800 @ 512 spp, unchanged. The
+    image the reference publishes was rendered from the same random numbers; what remains are the paths that fork where
+    libm's cosf/sinf and the correctly rounded ones differ in the last bit. Stated bound: PSNR >= 46 dB (measured 48.8;
+    an independent render at the same sample count reaches 39.7), mean difference <= 0.05/255 per channel."""
+    gpu_ctx.upload_scene(path_scene)
+    rgb, w = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_REFERENCE_TILE_STREAM)
+    assert w.min() >= 512
+    img = develop(rgb, w)
+    p_ref = psnr8(img, reference_png)
+    bias = np.abs((img.astype(np.float64) - reference_png.astype(np.float64)).mean(axis=(0, 1))).max()
+    assert p_ref >= 46.0, f"PSNR {p_ref:.2f} dB"
+    assert bias <= 0.05, f"mean difference {bias:.3f}/255"
