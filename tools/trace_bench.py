@@ -101,6 +101,32 @@ def main():
     order = torch.sort(octant * 3 + major, stable=True).indices
     run("inward/oct+axis", p[order], dhemi[order], schedules=(False,))
 
+    # what the path tracer's second bounce traces: hits only (compacted, pixel order), cosine-distributed about the
+    # surface normal that faces the incoming ray
+    tri = torch.tensor(scene.tri_p.reshape(-1, 3, 3), device=dev)
+    ng_all = torch.nn.functional.normalize(torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=1), dim=1)
+    run1("camera (for hits)", ocam.contiguous(), dcam.contiguous())
+    hitmask = prim >= 0
+    ph = (ocam + t.unsqueeze(1) * dcam)[hitmask]
+    nh = ng_all[prim[hitmask].long()]
+    nh = torch.where(((nh * dcam[hitmask]).sum(1) > 0).unsqueeze(1), -nh, nh)
+    dcos = torch.nn.functional.normalize(nh + torch.nn.functional.normalize(torch.randn(ph.shape, device=dev, generator=g), dim=1) * 0.999, dim=1)
+    m = ph.shape[0]
+    reps_idx = torch.arange(n, device=dev) % m   # pad to n rays by repeating the sequence
+    run("cosine", ph[reps_idx], dcos[reps_idx])
+    # third bounce: from the hit points of those, again cosine-distributed
+    ctx.set_trace_schedule("lockstep")
+    o2, d2 = ph[reps_idx].contiguous(), dcos[reps_idx].contiguous()
+    ctx.trace_closest_dev(n, o2.data_ptr(), d2.data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr())
+    ctx.synchronize()
+    h2 = prim >= 0
+    p2 = (o2 + t.unsqueeze(1) * d2)[h2]
+    n2 = ng_all[prim[h2].long()]
+    n2 = torch.where(((n2 * d2[h2]).sum(1) > 0).unsqueeze(1), -n2, n2)
+    dc2 = torch.nn.functional.normalize(n2 + torch.nn.functional.normalize(torch.randn(p2.shape, device=dev, generator=g), dim=1) * 0.999, dim=1)
+    idx2 = torch.arange(n, device=dev) % p2.shape[0]
+    run("cosine2", p2[idx2], dc2[idx2])
+
     o, d = raygen.incoherent_rays(scene.bounds, n, 3)
     run("uniform", torch.tensor(o, device=dev), torch.tensor(d, device=dev))
     ctx.close()
