@@ -90,15 +90,31 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the device path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in a rehearsal with fewer GPUs than ranks
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    # RCCL is the transport; "gloo" (RT_BENCH_BACKEND) only rehearses the multi-rank logic on a box with fewer GPUs than
+    # ranks, where RCCL refuses two ranks on one device - it stages the film through host memory and is not a measurement
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def reduce_to_rank0(tensor):
+        if backend == "nccl":
+            dist.reduce(tensor, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            staged = tensor.cpu()
+            dist.reduce(staged, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                tensor.copy_(staged)
 
     scene = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornellBox_path.npz"))
     cfg = scene.config.with_resolution(WIDTH, HEIGHT, spp=SPP_PER_STEP)
-    ctx = Context(local_rank)
+    ctx = Context(local_dev)
     ctx.upload_scene(scene)
     ctx.set_camera(cfg)
 
@@ -131,8 +147,8 @@ def main():
     if world > 1:
         # first use of the collectives (communicator set-up, channel buffers) belongs to the warm-up, not to the timed steps
         ctx.synchronize()
-        dist.reduce(rgb, dst=0, op=dist.ReduceOp.SUM)
-        dist.reduce(wsum, dst=0, op=dist.ReduceOp.SUM)
+        reduce_to_rank0(rgb)
+        reduce_to_rank0(wsum)
     fence()
     rgb.zero_()
     wsum.zero_()
@@ -143,14 +159,14 @@ def main():
     run(rank * K * P, (rank + 1) * K * P, spp_total)
     if world > 1:
         ctx.synchronize()   # the render runs on the library's own streams; RCCL runs on torch's
-        dist.reduce(rgb, dst=0, op=dist.ReduceOp.SUM)
-        dist.reduce(wsum, dst=0, op=dist.ReduceOp.SUM)
+        reduce_to_rank0(rgb)
+        reduce_to_rank0(wsum)
     fence()
     elapsed = time.perf_counter() - t0
 
     st = ctx.stats()
     local = torch.tensor([elapsed, float(st["rays_closest"] + st["rays_any"]), float(st["camera_samples"]), float(st["extend_rays"]),
-                          st["extend_ms"], float(st["extend_launches"])], dtype=torch.float64, device=dev)
+                          st["extend_ms"], float(st["extend_launches"])], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     tmax = local.clone()
     tsum = local.clone()
     if world > 1:
@@ -187,7 +203,7 @@ def main():
                 "spp_per_gpu": K * P,
                 "spp_total": spp_total,
                 "paths_in_flight_per_gpu": WIDTH * HEIGHT * P,
-                "parallelism": f"spp-sharded x{world}, one RCCL sum-reduce of the {WIDTH}x{HEIGHT}x4 float film",
+                "parallelism": f"spp-sharded x{world}, one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} sum-reduce of the {WIDTH}x{HEIGHT}x4 float film",
             },
             "rays_per_sample": rays / samples,
             "roofline": {
