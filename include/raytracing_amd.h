@@ -226,6 +226,17 @@ void *rt_stream(rt_context *ctx);
 int rt_get_stats(rt_context *ctx, rt_stats *out);
 int rt_reset_stats(rt_context *ctx);
 
+/* Diagnostics (no counterpart in the reference; host-side, no GPU needed for the first two) ----------------------- */
+
+/* The device code's correctly rounded sine / cosine, evaluated on the host: what stands in for libm's sinf / cosf in
+ * concentricSampleDisk (theta in [-pi/4, 3pi/4], Render/Sampler.cpp) and in the sphere code (any theta,
+ * Shape/SphereShape.cpp:217-222, 262-266). Tests compare them with a float64 evaluation rounded once. */
+void rt_debug_sincos_disk(float theta, float *sin_out, float *cos_out);
+void rt_debug_sincos_cr(float theta, float *sin_out, float *cos_out);
+/* Count passes the last Whitted render with RT_RNG_REFERENCE_TILE_STREAM needed to place every pixel in its tile's random
+ * stream (-1: the serial fallback ran; 0: no such render yet). */
+int rt_debug_whitted_passes(const rt_context *ctx);
+
 #ifdef __cplusplus
 }
 #endif

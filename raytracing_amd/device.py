@@ -16,6 +16,7 @@ EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_version", "rt_upload_scene", "rt_set_camera", "rt_trace_closest",
     "rt_trace_any", "rt_trace_closest_dev", "rt_trace_any_dev", "rt_render", "rt_render_dev", "rt_synchronize", "rt_stream",
     "rt_get_stats", "rt_reset_stats", "rt_set_option", "rt_develop", "rt_develop_dev", "rt_set_film",
+    "rt_debug_sincos_disk", "rt_debug_sincos_cr", "rt_debug_whitted_passes",
 ]
 
 
