@@ -170,6 +170,7 @@ int ensure_spill(rt_context *c) {
     if (c->dSpillRgb) (void)hipFree(c->dSpillRgb);
     if (c->dSpillW) (void)hipFree(c->dSpillW);
     c->dSpillRgb = c->dSpillW = nullptr;
+    c->spillPixels = 0;
     HIPCHK(c, hipMalloc((void **)&c->dSpillRgb, n * 3 * sizeof(float)));
     HIPCHK(c, hipMalloc((void **)&c->dSpillW, n * sizeof(float)));
     HIPCHK(c, hipMemset(c->dSpillRgb, 0, n * 3 * sizeof(float)));
@@ -439,6 +440,7 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
         if (c->pixelStateCap < need) {
             if (c->dPixelState) (void)hipFree(c->dPixelState);
             c->dPixelState = nullptr;
+            c->pixelStateCap = 0;
             HIPCHK(c, hipMalloc((void **)&c->dPixelState, need * sizeof(uint2)));
             c->pixelStateCap = need;
         }
