@@ -86,16 +86,30 @@ def renderer_for(scene: FlatScene, **kw):
 
 
 def main(argv=None):
-    """Like the reference's main(): the scene path comes from stdin when it is not given as an argument."""
-    import sys
-    argv = sys.argv[1:] if argv is None else argv
-    path = argv[0] if argv else input("Input the scene file: ").strip()
+    """Like the reference's main() (src/RayTracing.cpp:13-37): scene file in, Film "Filename" out; the scene path comes
+    from stdin when it is not given as an argument."""
+    import argparse
+    import time
+    ap = argparse.ArgumentParser(prog="python -m raytracing_amd", description=main.__doc__)
+    ap.add_argument("scene", nargs="?", help="scene JSON of the reference's format")
+    ap.add_argument("-o", "--output", help="PNG path (default: the film's Filename in the current directory)")
+    ap.add_argument("--spp", type=int, help="samples per pixel (default: the sampler's SPP)")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=0, help="seed of the counter streams")
+    ap.add_argument("--reference-stream", action="store_true",
+                    help="draw from the CPU renderer's per-tile PCG32 streams (reproduces its image; serial per tile, so "
+                         "seconds instead of milliseconds for the Path integrator). Whitted scenes use it by default.")
+    a = ap.parse_args(argv)
+    path = a.scene if a.scene else input("Input the scene file: ").strip()
     scene = load_scene_json(path)
-    r = renderer_for(scene)
+    r = renderer_for(scene, spp=a.spp, device_id=a.device, seed=a.seed,
+                     rng_mode=RT_RNG_REFERENCE_TILE_STREAM if a.reference_stream else None)
     r.preprocess(scene)
+    t0 = time.perf_counter()
     film = r.render(scene)
-    out = film.write_image_to_file(os.path.join(os.getcwd(), scene.config.filename))
-    print("wrote", out)
+    dt = time.perf_counter() - t0
+    out = film.write_image_to_file(a.output or os.path.join(os.getcwd(), scene.config.filename))
+    print(f"rendered in {dt:.3f} s, wrote {out}")
 
 
 __all__ = ["Film", "SamplerRenderer", "PathRenderer", "WhittedRenderer", "renderer_for", "main",

@@ -437,3 +437,39 @@ def test_path_tile_stream_reproduces_the_published_image(gpu_ctx, path_scene, re
     bias = np.abs((img.astype(np.float64) - reference_png.astype(np.float64)).mean(axis=(0, 1))).max()
     assert p_ref >= 46.0, f"PSNR {p_ref:.2f} dB"
     assert bias <= 0.05, f"mean difference {bias:.3f}/255"
+
+
+def test_scene_file_in_png_out(tmp_path):
+    """The reference's main() through this package (python -m raytracing_amd): a scene file written here (two quads from
+    OBJ files, one of them a luminaire, and a mirror sphere entity) is loaded, rendered by the renderer the file names
+    and written as the film's PNG; the Path renderer with counter streams and with the reference's tile stream must
+    agree statistically, and the Whitted renderer must run on the same file."""
+    import json
+    from raytracing_amd.pngio import read_png
+    from raytracing_amd.renderer import main
+    (tmp_path / "floor.obj").write_text("v -2 0 -2\nv 2 0 -2\nv 2 0 2\nv -2 0 2\nf 1 3 2\nf 1 4 3\n")
+    (tmp_path / "lamp.obj").write_text("v -0.5 2 -0.5\nv 0.5 2 -0.5\nv 0.5 2 0.5\nv -0.5 2 0.5\nf 1 2 3 4\n")
+    mesh = lambda f, extra=None: dict({"Type": "MeshEntity", "Filename": f, "Shape": {"Type": "Triangle"},
+                                       "Material": {"Type": "Lambertian", "R": [0.7, 0.6, 0.5]}}, **(extra or {}))
+    scene = {"Renderer": {"Type": "Path", "Depth": 4, "Sampler": {"Type": "Random", "SPP": 64},
+                          "Camera": {"Type": "Perspective", "Fov": 45, "Eye": [0, 1.2, -4], "Focus": [0, 0.6, 0], "WorldUp": [0, 1, 0],
+                                     "Film": {"Type": "Film", "Resolution": [96, 64], "Filename": "out.png", "Filter": {"Type": "Box"}}}},
+             "Entity": [mesh("floor.obj"),
+                        mesh("lamp.obj", {"Light": {"Type": "AreaDiffuse", "Radiance": [12, 12, 12], "TwoSided": True}}),
+                        {"Type": "Entity", "Shape": {"Type": "Sphere", "Radius": 0.5, "Transform": [0, 0, 0.5, 0]},
+                         "Material": {"Type": "Mirror", "R": [0.9, 0.9, 0.9]}}]}
+    sj = tmp_path / "scene.json"
+    sj.write_text(json.dumps(scene))
+    a, b = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    main([str(sj), "-o", a])
+    main([str(sj), "-o", b, "--reference-stream"])
+    ia, ib = read_png(a).astype(np.float64), read_png(b).astype(np.float64)
+    assert ia.shape == (64, 96, 3) and ia.max() > 100 and ia[50:, 40:56].mean() > 5     # lit floor under the lamp
+    assert abs(ia.mean() - ib.mean()) < 0.03 * ia.mean() + 0.5
+    assert psnr8(ia, ib) > 22.0    # two independent 64-spp renders of the same scene
+    scene["Renderer"]["Type"] = "Whitted"
+    sj.write_text(json.dumps(scene))
+    c = str(tmp_path / "c.png")
+    main([str(sj), "-o", c, "--spp", "4"])
+    ic = read_png(c)
+    assert ic.shape == (64, 96, 3) and ic.max() > 100
