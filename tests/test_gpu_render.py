@@ -473,3 +473,29 @@ def test_scene_file_in_png_out(tmp_path):
     main([str(sj), "-o", c, "--spp", "4"])
     ic = read_png(c)
     assert ic.shape == (64, 96, 3) and ic.max() > 100
+
+
+def test_tile_streams_follow_a_crop_window(gpu_ctx, path_scene):
+    """With "CropMin"/"CropMax" the 16x16 tiles, and with them the per-tile random streams, are laid over the cropped
+    sample bounds, not over the film (Render/Render.cpp:24-46): both integrators on the reference's sampler inside a
+    window whose origin and size are no multiples of 16, against the oracle."""
+    from dataclasses import replace
+    import oracle_lib
+    from raytracing_amd.scene import sample_bounds
+    base = path_scene.config.with_resolution(90, 70, spp=6)
+    crop = (13, 9, 78, 62)
+    cfg = replace(base, cropped_bounds=crop, sample_bounds=sample_bounds(crop, (0.5, 0.5)))
+    assert cfg.sample_bounds == crop
+    orc = Oracle(path_scene, cfg)
+    gpu_ctx.upload_scene(path_scene)
+    gpu_ctx.set_camera(cfg)
+    for integrator, depth in ((RT_INTEGRATOR_WHITTED, 3), (RT_INTEGRATOR_PATH, 6)):
+        grgb, gw = gpu_ctx.render(integrator=integrator, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=depth)
+        oracle_lib.set_trig_mode(True)
+        try:
+            crgb, cw, _ = orc.render(integrator=integrator, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=depth)
+        finally:
+            oracle_lib.set_trig_mode(False)
+        assert np.array_equal(gw, cw) and gw[9:62, 13:78].min() >= 6 and not gw[:9].any() and not gw[:, 78:].any()
+        neq = (grgb != crgb).any(axis=2)
+        assert np.count_nonzero(neq) <= 4 and np.abs(grgb - crgb).max() <= 2e-6 * max(1.0, np.abs(crgb).max())
