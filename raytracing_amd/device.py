@@ -20,10 +20,34 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bring their own HIP runtime. A process must run on one runtime: if this library pulled in the
+    system's first, a later `import torch` would find no GPU. When torch is installed and not yet imported, its runtime
+    is therefore loaded first (without importing torch); the dynamic loader then resolves this library against it, exactly
+    as when the caller imports torch first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def device_lib():
     """Loads libraytracing_amd.so. Raises if it has not been built (run `make device`)."""
     global _dev
     if _dev is None:
+        _share_hip_runtime_with_torch()
         path = os.environ.get("RT_AMD_DEVICE_LIB") or os.path.join(_LIB_DIR, "libraytracing_amd.so")   # override: experiments
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with `make device` (or __graft_entry__.build()); "

@@ -499,3 +499,23 @@ def test_tile_streams_follow_a_crop_window(gpu_ctx, path_scene):
         assert np.array_equal(gw, cw) and gw[9:62, 13:78].min() >= 6 and not gw[:9].any() and not gw[:, 78:].any()
         neq = (grgb != crgb).any(axis=2)
         assert np.count_nonzero(neq) <= 4 and np.abs(grgb - crgb).max() <= 2e-6 * max(1.0, np.abs(crgb).max())
+
+
+def test_throughput_floor(gpu_ctx, path_scene):
+    """Guard against accidental slow paths (a kernel variant not selected, scene tables not staged in LDS, a lost
+    overlap): the wavefront path tracer on the benchmark workload must stay above a floor far below what it measures
+    (9.9 G rays/s on an MI355X), and the tables of this scene must live in LDS."""
+    import time
+    cfg = path_scene.config.with_resolution(1920, 1080, spp=16)
+    gpu_ctx.upload_scene(path_scene)
+    gpu_ctx.set_camera(cfg)
+    kw = dict(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=1, spp=16, max_depth=15)
+    rgb, w = gpu_ctx.render(**kw)                       # warm-up: allocates the queues
+    gpu_ctx.reset_stats()
+    t0 = time.perf_counter()
+    gpu_ctx.render(rgb_sum=rgb, weight_sum=w, **kw)     # host buffers: the time includes 2 x 33 MB over PCIe
+    dt = time.perf_counter() - t0
+    st = gpu_ctx.stats()
+    mrays = (st["rays_closest"] + st["rays_any"]) / dt / 1e6
+    assert float(w.min()) >= 32.0
+    assert mrays > 2500, f"{mrays:.0f} Mrays/s"
