@@ -519,3 +519,35 @@ def test_throughput_floor(gpu_ctx, path_scene):
     mrays = (st["rays_closest"] + st["rays_any"]) / dt / 1e6
     assert float(w.min()) >= 32.0
     assert mrays > 2500, f"{mrays:.0f} Mrays/s"
+
+
+def test_edge_configurations(gpu_ctx, path_scene):
+    """Corners of the parameter space against the oracle: a scene without lights (nothing to sample, black image), depth 0
+    (emission of directly visible lights only), one sample per pixel, and a sample count the pass size does not divide
+    (the split into passes must not show in the sums)."""
+    from dataclasses import replace
+    import oracle_lib
+    cfg = path_scene.config.with_resolution(64, 48, spp=5)
+    dark = replace(path_scene, light_id=np.full(path_scene.n_prims, -1, np.int32), lights=path_scene.lights[:0])
+    gpu_ctx.upload_scene(dark)
+    gpu_ctx.set_camera(cfg)
+    for integrator in (RT_INTEGRATOR_PATH, RT_INTEGRATOR_WHITTED):
+        rgb, w = gpu_ctx.render(integrator=integrator, rng_mode=RT_RNG_COUNTER, max_depth=5)
+        assert not rgb.any() and (w == 5).all()
+    orc = Oracle(path_scene, cfg)
+    gpu_ctx.upload_scene(path_scene)
+    gpu_ctx.set_camera(cfg)
+    oracle_lib.set_trig_mode(True)
+    try:
+        for depth, spp in ((0, 5), (1, 1), (7, 5)):
+            crgb, cw, _ = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=depth, spp=spp)
+            for per_pass in (0, 2, 3):
+                grgb, gw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=depth, spp=spp,
+                                          spp_per_pass=per_pass)
+                assert np.array_equal(gw, cw)
+                neq = (grgb != crgb).any(axis=2)
+                assert np.count_nonzero(neq) <= 2, (depth, spp, per_pass, np.count_nonzero(neq))
+            if depth == 0:
+                assert (crgb.sum(axis=2) > 0).mean() < 0.05   # only the luminaire's pixels
+    finally:
+        oracle_lib.set_trig_mode(False)
