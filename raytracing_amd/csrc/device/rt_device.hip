@@ -15,7 +15,7 @@
 #include "kernels.h"
 
 #ifndef RT_PIPES
-#define RT_PIPES 2   // wavefront pipelines (streams + buffer sets) that overlap consecutive passes
+#define RT_PIPES 3   // wavefront pipelines (streams + buffer sets) that overlap consecutive passes: 2 -> 3 gains 2 %, 4 loses 4 %
 #endif
 
 namespace {

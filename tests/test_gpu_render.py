@@ -504,7 +504,7 @@ def test_tile_streams_follow_a_crop_window(gpu_ctx, path_scene):
 def test_throughput_floor(gpu_ctx, path_scene):
     """Guard against accidental slow paths (a kernel variant not selected, scene tables not staged in LDS, a lost
     overlap): the wavefront path tracer on the benchmark workload must stay above a floor far below what it measures
-    (9.9 G rays/s on an MI355X), and the tables of this scene must live in LDS."""
+    (10 G rays/s on an MI355X), and the tables of this scene must live in LDS."""
     import time
     cfg = path_scene.config.with_resolution(1920, 1080, spp=16)
     gpu_ctx.upload_scene(path_scene)
