@@ -60,8 +60,8 @@ struct rt_context {
     size_t extendEventsUsed = 0;
     double renderMs = 0;
 
-    // path tracer pipelines: consecutive passes alternate between two sets of buffers on two streams, so the
-    // small late-bounce launches of one pass overlap the large early-bounce launches of the next
+    // path tracer pipelines: consecutive passes rotate through kPipes sets of buffers, each on its own stream, so the
+    // small late-bounce launches of one pass overlap the large early-bounce launches of the next ones
     static constexpr int kPipes = RT_PIPES;
     PathBuffers pb[kPipes]{};
     hipStream_t pipeStream[kPipes] = {};
@@ -327,7 +327,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     const size_t lds = trace_lds_bytes(c), ldsStream = stream_lds_bytes_of(c);
     const int grid = c->gridBlocks;
     // scenes in HBM: the extend and shadow kernels regroup rays inside the wave (dstream.h); their static work split
-    // assumes a resident grid, so the passes then run one after the other instead of on two overlapping streams
+    // assumes a resident grid, so the passes then run one after the other instead of on overlapping streams
     const bool streamTrace = use_stream_schedule(c);
     const int pipesInUse = (streamTrace || std::getenv("RT_AMD_SINGLE_PIPE")) ? 1 : rt_context::kPipes;
 
@@ -395,7 +395,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
         lastPipe = k;
         HIPCHK(c, hipGetLastError());
     }
-    // join: the context's stream continues after both pipelines
+    // join: the context's stream continues after all pipelines
     for (int k = 0; k < rt_context::kPipes; ++k) {
         HIPCHK(c, hipEventRecord(c->mainReady, c->pipeStream[k]));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->mainReady, 0));
