@@ -114,6 +114,20 @@ def main():
     m = ph.shape[0]
     reps_idx = torch.arange(n, device=dev) % m   # pad to n rays by repeating the sequence
     run("cosine", ph[reps_idx], dcos[reps_idx])
+    # the same rays grouped by the primitive they start on, and by primitive and direction octant (global stable sorts:
+    # an upper bound on what binning the queue appends could give)
+    ctx.set_trace_schedule("lockstep")
+    ctx.trace_closest_dev(n, ocam.contiguous().data_ptr(), dcam.contiguous().data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr())
+    ctx.synchronize()
+    start_prim = prim[hitmask][reps_idx].clone()
+    oc, dc = ph[reps_idx], dcos[reps_idx]
+    order = torch.sort(start_prim, stable=True).indices
+    run("cosine/prim", oc[order], dc[order], schedules=(False,))
+    octc = (dc[:, 0] > 0).int() + 2 * (dc[:, 1] > 0).int() + 4 * (dc[:, 2] > 0).int()
+    order = torch.sort(start_prim * 8 + octc, stable=True).indices
+    run("cosine/prim+oct", oc[order], dc[order], schedules=(False,))
+    order = torch.sort(octc, stable=True).indices
+    run("cosine/oct", oc[order], dc[order], schedules=(False,))
     # third bounce: from the hit points of those, again cosine-distributed
     ctx.set_trace_schedule("lockstep")
     o2, d2 = ph[reps_idx].contiguous(), dcos[reps_idx].contiguous()
