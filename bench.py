@@ -169,7 +169,7 @@ def main():
     # kernels of three passes share the CUs, which is faster overall but stretches every single launch.
     exclusive = None
     if rank == 0:
-        os.environ["RT_AMD_SINGLE_PIPE"] = "1"
+        ctx.set_pipelines(1)
         try:
             ctx.reset_stats()
             run(0, P, P)
@@ -178,7 +178,7 @@ def main():
             if sx["extend_ms"] > 0:
                 exclusive = (float(sx["extend_rays"]), sx["extend_ms"], max(1, sx["extend_launches"]))
         finally:
-            del os.environ["RT_AMD_SINGLE_PIPE"]
+            ctx.set_pipelines(3)
     local = torch.tensor([elapsed, float(st["rays_closest"] + st["rays_any"]), float(st["camera_samples"]), float(st["extend_rays"]),
                           st["extend_ms"], float(st["extend_launches"])], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     tmax = local.clone()

@@ -139,6 +139,11 @@ typedef struct rt_stats {
     double extend_ms;
     uint64_t extend_rays;      /* rays processed by those launches */
     double render_ms;          /* wall time of rt_render* calls (host clock, device-synchronised) */
+    /* state of the context (not counters; rt_reset_stats leaves them alone) */
+    uint64_t queue_bytes_per_pipeline;  /* device memory of one wavefront pipeline's queues and per-path state; 0 before the first Path render */
+    uint64_t queue_paths;               /* paths in flight those queues are sized for */
+    int32_t pipelines;                  /* RT_OPTION_PIPELINES */
+    int32_t scene_in_lds;               /* 1 when the traversal tables of the uploaded scene are staged in LDS by every tracing workgroup */
 } rt_stats;
 
 /* Library / context ------------------------------------------------------------------------- */
@@ -190,8 +195,12 @@ int rt_trace_any(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d
  *   RT_SCHEDULE_STREAM:         lanes pick up the next ray as soon as theirs ends. Fastest for incoherent rays and for
  *                               scenes in HBM (1 M-triangle soup, incoherent rays: 0.63 vs 0.36 G rays/s).
  * Applies to rt_trace_* and, for scenes in HBM, to the extend and shadow stages of rt_render. */
-enum { RT_OPTION_TRACE_SCHEDULE = 1 };
+enum { RT_OPTION_TRACE_SCHEDULE = 1, RT_OPTION_PIPELINES = 2 };
 enum { RT_SCHEDULE_AUTO = 0, RT_SCHEDULE_LOCKSTEP = 1, RT_SCHEDULE_STREAM = 2 };
+/* RT_OPTION_PIPELINES: how many passes of the wavefront path tracer overlap on separate streams (1..RT_MAX_PIPELINES,
+ * default RT_MAX_PIPELINES). 1 runs the passes one after the other, which is how a single kernel's launch time is
+ * measured without other passes sharing the CUs. Results do not depend on it. */
+enum { RT_MAX_PIPELINES = 3 };
 int rt_set_option(rt_context *ctx, int option, int value);
 
 /* Same, all pointers in device memory, asynchronous on the context's stream (call rt_synchronize). */
@@ -215,7 +224,10 @@ int rt_render_dev(rt_context *ctx, const rt_render_params *params, float *rgb_su
 /* Film development on the device: what Film::mergeFilmTile + Film::writeImageToFile do to the sums before the PNG is
  * written (Object/Film.cpp:98-167: RGB -> XYZ -> RGB, divide by weight_sum, clamp at 0, multiply by the film's
  * "Scale", sRGB curve, 8 bits). rgb8 receives width*height*3 bytes, row-major; the film size is the one given to
- * rt_set_camera. Encoding the PNG stays with the caller. rt_develop takes host buffers and blocks. */
+ * rt_set_camera. Encoding the PNG stays with the caller. rt_develop takes host buffers and blocks.
+ * The one libm call on this path is the sRGB curve's powf (Utils/Base.h:50-55), whose last bit is implementation-defined:
+ * the device evaluates pow in double and rounds once, so against a host libm (rt_host_develop, or the reference itself) a
+ * byte may differ by ONE code where 255 * g + 0.5 sits on an integer (measured: fewer than 1 byte in 10 000). */
 int rt_develop(rt_context *ctx, const float *rgb_sum, const float *weight_sum, float film_scale, uint8_t *rgb8);
 int rt_develop_dev(rt_context *ctx, const float *rgb_sum_dev, const float *weight_sum_dev, float film_scale, uint8_t *rgb8_dev);
 

@@ -813,6 +813,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_develop(size_t nPix, const float *
 // ---------------------------------------------------------------------------------------------------
 // Whitted integrator (Render/Render.cpp:106-152, 473-532)
 // ---------------------------------------------------------------------------------------------------
+// Frames of the unrolled recursion. rt_render refuses a Whitted job with max_depth above this (RT_ERR_UNSUPPORTED), so
+// the `sp < RT_WHITTED_MAX_FRAMES` test in whitted_li never decides a result; it only keeps fr[] in bounds.
 #define RT_WHITTED_MAX_FRAMES 32
 
 struct WFrame {

@@ -15,7 +15,7 @@
 #include "kernels.h"
 
 #ifndef RT_PIPES
-#define RT_PIPES 3   // wavefront pipelines (streams + buffer sets) that overlap consecutive passes: 2 -> 3 gains 2 %, 4 loses 4 %
+#define RT_PIPES RT_MAX_PIPELINES   // wavefront pipelines (streams + buffer sets) that overlap consecutive passes: 2 -> 3 gains 2 %, 4 loses 4 %
 #endif
 
 namespace {
@@ -56,6 +56,7 @@ struct rt_context {
     // stats
     unsigned long long *dStats = nullptr;
     int traceSchedule = RT_SCHEDULE_AUTO;
+    int pipelines = RT_PIPES;   // RT_OPTION_PIPELINES
     std::vector<EventPair> extendEvents;
     size_t extendEventsUsed = 0;
     double renderMs = 0;
@@ -68,12 +69,14 @@ struct rt_context {
     hipEvent_t pipeFilmDone[kPipes] = {};
     hipEvent_t mainReady = nullptr;
     size_t pbCapacity = 0;
+    size_t pbBytesPerPipe = 0;
     int pbDepth = 0;
     std::vector<void *> pbAllocs;
 
     // film spill + whitted state
     float *dSpillRgb = nullptr, *dSpillW = nullptr;
     size_t spillPixels = 0;
+    bool spillDirty = false;   // the last render returned an error: the spill buffers may hold its samples
     uint2 *dPixelState = nullptr;
     size_t pixelStateCap = 0;
 };
@@ -107,6 +110,7 @@ void free_path_buffers(rt_context *c) {
     for (void *p : c->pbAllocs) (void)hipFree(p);
     c->pbAllocs.clear();
     c->pbCapacity = 0;
+    c->pbBytesPerPipe = 0;
     c->pbDepth = 0;
     for (auto &pb : c->pb) pb = PathBuffers{};
 }
@@ -166,7 +170,14 @@ size_t stream_lds_bytes_of(const rt_context *c) { return c->ldsScene ? stream_ld
 
 int ensure_spill(rt_context *c) {
     const size_t n = (size_t)c->cam.width * c->cam.height;
-    if (c->spillPixels == n && c->dSpillRgb) return RT_OK;
+    if (c->spillPixels == n && c->dSpillRgb) {
+        if (c->spillDirty) {   // leftovers of a render that failed half way must not reach the next film
+            HIPCHK(c, hipMemsetAsync(c->dSpillRgb, 0, n * 3 * sizeof(float), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->dSpillW, 0, n * sizeof(float), c->stream));
+            c->spillDirty = false;
+        }
+        return RT_OK;
+    }
     if (c->dSpillRgb) (void)hipFree(c->dSpillRgb);
     if (c->dSpillW) (void)hipFree(c->dSpillW);
     c->dSpillRgb = c->dSpillW = nullptr;
@@ -176,15 +187,18 @@ int ensure_spill(rt_context *c) {
     HIPCHK(c, hipMemset(c->dSpillRgb, 0, n * 3 * sizeof(float)));
     HIPCHK(c, hipMemset(c->dSpillW, 0, n * sizeof(float)));
     c->spillPixels = n;
+    c->spillDirty = false;
     return RT_OK;
 }
 
 int ensure_path_buffers(rt_context *c, size_t nPaths, int maxDepth) {
     if (c->pbCapacity >= nPaths && c->pbDepth >= maxDepth) return RT_OK;
     free_path_buffers(c);
+    size_t total = 0;
     auto alloc = [&](void **p, size_t bytes) -> int {
         HIPCHK(c, hipMalloc(p, bytes));
         c->pbAllocs.push_back(*p);
+        total += bytes;
         return RT_OK;
     };
     int rc;
@@ -205,6 +219,7 @@ int ensure_path_buffers(rt_context *c, size_t nPaths, int maxDepth) {
         if ((rc = alloc((void **)&pb.counts, (size_t)(maxDepth + 2) * RT_CNT_PER_BOUNCE * RT_CNT_STRIDE * sizeof(uint32_t)))) return rc;
     }
     c->pbCapacity = nPaths;
+    c->pbBytesPerPipe = total / rt_context::kPipes;
     c->pbDepth = maxDepth;
     return RT_OK;
 }
@@ -329,7 +344,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     // scenes in HBM: the extend and shadow kernels regroup rays inside the wave (dstream.h); their static work split
     // assumes a resident grid, so the passes then run one after the other instead of on overlapping streams
     const bool streamTrace = use_stream_schedule(c);
-    const int pipesInUse = (streamTrace || std::getenv("RT_AMD_SINGLE_PIPE")) ? 1 : rt_context::kPipes;
+    const int pipesInUse = streamTrace ? 1 : c->pipelines;
 
     // what camera_origin() returns on the device: xf_apply(c2w, (0, 0, 0), 1) with the same operation order
     float co[4];
@@ -502,8 +517,13 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
 }
 
 int render_dispatch(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
-    if (p->integrator == RT_INTEGRATOR_WHITTED) return render_whitted(c, p, rgb, wsum);
-    return p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM ? render_path_tile_stream(c, p, rgb, wsum) : render_path(c, p, rgb, wsum);
+    int rc;
+    if (p->integrator == RT_INTEGRATOR_WHITTED) rc = render_whitted(c, p, rgb, wsum);
+    else rc = p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM ? render_path_tile_stream(c, p, rgb, wsum) : render_path(c, p, rgb, wsum);
+    // every renderer ends with k_merge_spill, which leaves the spill buffers zeroed; after an error return in between
+    // they may hold samples of the failed render, and the next render clears them first (ensure_spill)
+    if (rc != RT_OK) c->spillDirty = true;
+    return rc;
 }
 
 }  // namespace
@@ -529,7 +549,7 @@ int rt_create(int device_id, rt_context **out) {
     c->device = device_id;
     auto bail = [&](const char *what, hipError_t err) {
         g_create_err = std::string(what) + ": " + hipGetErrorString(err);
-        delete c;
+        rt_destroy(c);   // frees whatever has been created so far
         return RT_ERR_HIP;
     };
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
@@ -600,6 +620,10 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
         if (d->lights[i].prim_id < 0 || (uint32_t)d->lights[i].prim_id >= d->n_prims) return fail(c, RT_ERR_INVALID_ARG, "light prim_id out of range");
     for (uint32_t i = 0; i < d->n_materials; ++i)
         if (d->materials[i].type < RT_MAT_LAMBERTIAN || d->materials[i].type > RT_MAT_GLASS) return fail(c, RT_ERR_INVALID_ARG, "unknown material type");
+    // Depth of every node below the root (children have larger indices than their parent, so one forward pass fills it).
+    // An interior node at depth k can find k entries pending on the todo stack and push one more: the traversal keeps
+    // RT_STACK_TOTAL entries, like the reference's todo[64] (Accelerators/KDTree.cpp:396-398).
+    std::vector<uint8_t> depth(d->n_nodes, 0);
     for (uint32_t i = 0; i < d->n_nodes; ++i) {
         const uint32_t w0 = d->nodes[2 * i], w1 = d->nodes[2 * i + 1];
         if ((w1 & 3u) == 3u) {
@@ -609,6 +633,8 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
         } else {
             const uint32_t above = w1 >> 2;
             if (i + 1 >= d->n_nodes || above >= d->n_nodes || above <= i) return fail(c, RT_ERR_INVALID_ARG, "interior node child out of range");
+            if (depth[i] >= RT_STACK_TOTAL) return fail(c, RT_ERR_INVALID_ARG, "KD-tree deeper than the 64-entry todo stack");
+            depth[i + 1] = depth[above] = (uint8_t)(depth[i] + 1);
         }
     }
     for (uint32_t i = 0; i < d->n_leaf_idx; ++i)
@@ -936,6 +962,11 @@ int rt_set_option(rt_context *c, int option, int value) {
         c->traceSchedule = value;
         return RT_OK;
     }
+    if (option == RT_OPTION_PIPELINES) {
+        if (value < 1 || value > rt_context::kPipes) return fail(c, RT_ERR_INVALID_ARG, "pipelines must be 1..RT_MAX_PIPELINES");
+        c->pipelines = value;
+        return RT_OK;
+    }
     return fail(c, RT_ERR_INVALID_ARG, "unknown option");
 }
 
@@ -963,6 +994,10 @@ int rt_get_stats(rt_context *c, rt_stats *out) {
     out->extend_launches = c->extendEventsUsed;
     out->extend_ms = ms;
     out->render_ms = c->renderMs;
+    out->queue_bytes_per_pipeline = c->pbBytesPerPipe;
+    out->queue_paths = c->pbCapacity;
+    out->pipelines = c->pipelines;
+    out->scene_in_lds = c->haveScene && c->ldsScene ? 1 : 0;
     return RT_OK;
 }
 

@@ -206,6 +206,10 @@ class Context:
         value = {"auto": 0, "lockstep": 1, "stream": 2}[schedule]
         self._check(self._lib.rt_set_option(self._h, 1, value))
 
+    def set_pipelines(self, n):
+        """How many passes of the wavefront path tracer overlap on separate streams (1..3)."""
+        self._check(self._lib.rt_set_option(self._h, 2, int(n)))
+
     def develop(self, rgb_sum, weight_sum, film_scale=1.0):
         """Film sums (host arrays of the camera's size) -> (H, W, 3) uint8 sRGB image, computed on the device."""
         rgb_sum = np.ascontiguousarray(rgb_sum, np.float32)

@@ -149,3 +149,28 @@ def test_sphere_scene_closest_and_any(gpu_ctx, sphere_scene):
     tmax = np.random.RandomState(14).uniform(0, 800, len(p)).astype(np.float32)
     assert np.array_equal(gpu_ctx.trace_any(p, d2, tmax), orc.trace_any(p, d2, tmax))
     assert np.array_equal(gpu_ctx.trace_any(o, d), orc.trace_any(o, d))
+
+
+def test_upload_rejects_a_tree_deeper_than_the_todo_stack(gpu_ctx, path_scene):
+    """The traversal keeps 64 todo entries like the reference's todo[64] (Accelerators/KDTree.cpp:396-398); a caller's
+    tree that could need more is refused at upload instead of overrunning the stack on the device."""
+    import copy
+    from raytracing_amd.device import RtError
+
+    def chain(n_interior):
+        # interior node i: split plane x = 1 + i, below child i + 1, above child = the shared empty leaf at the end
+        nodes = np.zeros((n_interior + 2, 2), np.uint32)
+        for i in range(n_interior):
+            nodes[i, 0] = np.float32(1 + i).view(np.uint32)
+            nodes[i, 1] = (n_interior + 1) << 2
+        nodes[n_interior] = (0, 3)        # empty leaves
+        nodes[n_interior + 1] = (0, 3)
+        s = copy.copy(path_scene)
+        s.nodes = nodes
+        s.leaf_idx = np.zeros(0, np.int32)
+        return s
+
+    gpu_ctx.upload_scene(chain(64))     # deepest interior node at depth 63: at most 64 entries
+    with pytest.raises(RtError, match="deeper"):
+        gpu_ctx.upload_scene(chain(65))
+    gpu_ctx.upload_scene(path_scene)

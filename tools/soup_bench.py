@@ -16,7 +16,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from raytracing_amd.device import Context  # noqa: E402
-from raytracing_amd.scene import FlatScene, build_scene, camera_ray, make_lights, make_materials  # noqa: E402
+from raytracing_amd.scene import FlatScene, camera_ray  # noqa: E402
 import raygen  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
@@ -27,15 +27,8 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 22
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     t0 = time.perf_counter()
-    tri = raygen.triangle_soup(n_tris, seed=4)
-    # the cornellBox luminaire (two emissive triangles under the ceiling) and the cornellBox camera at 1080p
-    lum = np.array([[343, 548.7, 227, 343, 548.7, 332, 213, 548.7, 332], [343, 548.7, 227, 213, 548.7, 332, 213, 548.7, 227]], np.float32)
-    tri = np.concatenate([tri, lum])
-    light_id = np.full(n_tris + 2, -1, np.int32)
-    light_id[n_tris:] = [0, 1]
-    cfg = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornellBox_path.npz")).config.with_resolution(1920, 1080, spp=4)
-    scene = build_scene(tri, np.zeros(n_tris + 2, np.int32), make_materials([(0, (0.73, 0.73, 0.73), 1.0)]), light_id=light_id,
-                        lights=make_lights([(n_tris, (17, 12, 4), 0), (n_tris + 1, (17, 12, 4), 0)]), config=cfg)
+    base = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornellBox_path.npz")).config
+    scene, cfg = raygen.soup_scene(n_tris, base)
     build_s = time.perf_counter() - t0
     print(f"# soup: {n_tris} triangles, {len(scene.nodes)} nodes, {len(scene.leaf_idx)} leaf indices, build {build_s:.1f} s "
           f"({scene.tree_stats})", flush=True)
