@@ -78,7 +78,7 @@ def test_connected_mesh_ties_and_mixed_materials(gpu_ctx, path_scene):
         oracle_lib.set_trig_mode(False)
     wrgb_c, ww_c, wst = orc.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=8, spp=2)
     assert _mean(crgb, cw).mean() > 0.01 and st["rays_closest"] > 1.5 * 96 * 72 * 8
-    assert wst["rays_closest"] > 1.3 * 96 * 72 * 2, "the specular recursion must have happened"
+    assert wst["rays_closest"] > 1.15 * 96 * 72 * 2, "the specular recursion must have happened"
     images = {}
     try:
         for schedule in ("lockstep", "stream"):
