@@ -221,6 +221,19 @@ int rt_render(rt_context *ctx, const rt_render_params *params, float *rgb_sum, f
  * queued on the context's stream (rt_synchronize to wait). */
 int rt_render_dev(rt_context *ctx, const rt_render_params *params, float *rgb_sum_dev, float *weight_sum_dev);
 
+/* rt_render_dev for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc). No counterpart in the reference. The call allocates nothing, on the device or through any library: the
+ * wavefront queues, queue counters, film spill buffers and statistics counters that rt_render_dev keeps in memory the
+ * context allocates on demand live here in a fixed array inside the library's code object, RT_NOALLOC_SCRATCH_MB per GPU,
+ * held from the moment the library is loaded on a GPU until the process ends. Same kernels, same results as rt_render_dev.
+ * Limits (RT_ERR_UNSUPPORTED beyond them): film and sample bounds of at most RT_NOALLOC_MAX_PATHS pixels (one sample per
+ * pixel in flight at that size, more for smaller films), max_depth <= RT_NOALLOC_MAX_DEPTH, rng_mode RT_RNG_COUNTER,
+ * collect_stats 0; one pipeline (passes run one after the other). Rays it traces are not added to rt_get_stats.
+ * All contexts on one GPU share that GPU's array: calls that overlap on one GPU race - run them one at a time
+ * (rt_synchronize between calls on different contexts of the same GPU; calls on one context are ordered by its stream). */
+enum { RT_NOALLOC_MAX_PATHS = 1 << 18, RT_NOALLOC_MAX_DEPTH = 64, RT_NOALLOC_SCRATCH_MB = 73 };
+int rt_render_noalloc_dev(rt_context *ctx, const rt_render_params *params, float *rgb_sum_dev, float *weight_sum_dev);
+
 /* Film development on the device: what Film::mergeFilmTile + Film::writeImageToFile do to the sums before the PNG is
  * written (Object/Film.cpp:98-167: RGB -> XYZ -> RGB, divide by weight_sum, clamp at 0, multiply by the film's
  * "Scale", sRGB curve, 8 bits). rgb8 receives width*height*3 bytes, row-major; the film size is the one given to

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <limits>
 #include <vector>
@@ -18,9 +19,50 @@
 #define RT_PIPES RT_MAX_PIPELINES   // wavefront pipelines (streams + buffer sets) that overlap consecutive passes: 2 -> 3 gains 2 %, 4 loses 4 %
 #endif
 
+// ---------------------------------------------------------------------------------------------------
+// Scratch of rt_render_noalloc_dev: one array per GPU, part of the code object, so the entry point never allocates.
+// Layout (byte offsets, all multiples of 256):
+//   [statistics counters][queue counters][film spill rgb][film spill weight][one wavefront pipeline's queues]
+// Host code never uses the array's name as an address: rt_create asks the runtime where the array lives on its device
+// (hipGetSymbolAddress) and everything below goes through that pointer.
+// ---------------------------------------------------------------------------------------------------
+namespace noalloc {
+constexpr size_t kMaxPaths = RT_NOALLOC_MAX_PATHS;
+constexpr size_t kMaxDepth = RT_NOALLOC_MAX_DEPTH;
+constexpr size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+constexpr size_t kStatsOff = 0;
+constexpr size_t kCountsOff = kStatsOff + align256(ST_COUNT * sizeof(unsigned long long));
+constexpr size_t kCountsBytes = (kMaxDepth + 2) * RT_CNT_PER_BOUNCE * RT_CNT_STRIDE * sizeof(uint32_t);
+constexpr size_t kSpillRgbOff = kCountsOff + align256(kCountsBytes);
+constexpr size_t kSpillWOff = kSpillRgbOff + align256(kMaxPaths * 3 * sizeof(float));
+constexpr size_t kQueuesOff = kSpillWOff + align256(kMaxPaths * sizeof(float));
+constexpr size_t kQueueVecPerPath = 11 + 6;   // PathBuffers: 11 float4 arrays + the 6-float4 probe record
+constexpr size_t kBytes = kQueuesOff + kMaxPaths * kQueueVecPerPath * 16;
+constexpr int kMaxDevices = 64;
+}  // namespace noalloc
+
+static_assert(noalloc::kBytes <= ((size_t)RT_NOALLOC_SCRATCH_MB << 20), "the header states the size of the scratch array");
+static __device__ __align__(256) unsigned char scratch[noalloc::kBytes];
+
 namespace {
 
 std::string g_create_err;
+std::mutex g_scratchMutex;
+unsigned char *g_scratchPtr[noalloc::kMaxDevices] = {};   // device address of `scratch` on each GPU, set by rt_create
+
+// The calling thread's current device must be `device`.
+hipError_t scratch_address(int device, unsigned char **out) {
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (device < 0 || device >= noalloc::kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_scratchPtr[device]) {
+        void *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratchPtr[device] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratchPtr[device];
+    return hipSuccess;
+}
 
 struct EventPair {
     hipEvent_t a, b;
@@ -76,6 +118,7 @@ struct rt_context {
     // film spill + whitted state
     float *dSpillRgb = nullptr, *dSpillW = nullptr;
     size_t spillPixels = 0;
+    unsigned char *scratchPtr = nullptr;   // this GPU's copy of the static scratch array (rt_render_noalloc_dev)
     bool spillDirty = false;   // the last render returned an error: the spill buffers may hold its samples
     uint2 *dPixelState = nullptr;
     size_t pixelStateCap = 0;
@@ -300,6 +343,17 @@ int trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, con
     return RT_OK;
 }
 
+// Where a render keeps what it needs beyond its inputs and outputs: the context's own allocations (rt_render*), or
+// this GPU's static scratch array (rt_render_noalloc_dev).
+struct RenderScratch {
+    PathBuffers *pb;        // nPipes sets of wavefront queues
+    int nPipes;
+    size_t capacityPaths;   // paths each set holds
+    float *spillRgb, *spillW;
+    unsigned long long *stats;
+    bool timeExtend;        // HIP events around the extend launches (the events are created on demand)
+};
+
 int check_render_args(rt_context *c, const rt_render_params *p) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (!p) return fail(c, RT_ERR_INVALID_ARG, "params is NULL");
@@ -319,7 +373,7 @@ int check_render_args(rt_context *c, const rt_render_params *p) {
     return RT_OK;
 }
 
-int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsum, const RenderScratch *fixed) {
     const CameraDev &cam = c->cam;
     const uint32_t sbW = (uint32_t)(cam.sb[2] - cam.sb[0]), sbH = (uint32_t)(cam.sb[3] - cam.sb[1]);
     const uint64_t nPix = (uint64_t)sbW * sbH;
@@ -330,21 +384,30 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     if (nPix * (uint64_t)sppPass >= (1ull << 30)) sppPass = (int)std::max<uint64_t>(1, ((1ull << 30) - 1) / nPix);
     if (nPix >= (1ull << 30)) return fail(c, RT_ERR_UNSUPPORTED, "film too large");
     int rc;
-    // the queues are sized for a 288 GB part; on a device with less free memory fall back to fewer samples in flight
-    while ((rc = ensure_path_buffers(c, nPix * (uint64_t)sppPass, p->max_depth)) != RT_OK) {
-        free_path_buffers(c);
-        (void)hipGetLastError();
-        if (sppPass == 1 || p->spp_per_pass > 0) return rc;   // an explicit request is not second-guessed
-        sppPass = (sppPass + 1) / 2;
+    RenderScratch own;
+    if (fixed) {
+        // a fixed set of queues: as many samples per pixel in flight as fit
+        if (nPix > fixed->capacityPaths) return fail(c, RT_ERR_UNSUPPORTED, "sample bounds hold more pixels than the scratch holds paths");
+        sppPass = (int)std::min<uint64_t>((uint64_t)sppPass, fixed->capacityPaths / nPix);
+    } else {
+        // the queues are sized for a 288 GB part; on a device with less free memory fall back to fewer samples in flight
+        while ((rc = ensure_path_buffers(c, nPix * (uint64_t)sppPass, p->max_depth)) != RT_OK) {
+            free_path_buffers(c);
+            (void)hipGetLastError();
+            if (sppPass == 1 || p->spp_per_pass > 0) return rc;   // an explicit request is not second-guessed
+            sppPass = (sppPass + 1) / 2;
+        }
+        if ((rc = ensure_spill(c))) return rc;
+        own = RenderScratch{c->pb, rt_context::kPipes, c->pbCapacity, c->dSpillRgb, c->dSpillW, c->dStats, true};
     }
-    if ((rc = ensure_spill(c))) return rc;
+    const RenderScratch &rs = fixed ? *fixed : own;
     const bool stats = p->collect_stats != 0;
     const size_t lds = trace_lds_bytes(c), ldsStream = stream_lds_bytes_of(c);
     const int grid = c->gridBlocks;
     // scenes in HBM: the extend and shadow kernels regroup rays inside the wave (dstream.h); their static work split
     // assumes a resident grid, so the passes then run one after the other instead of on overlapping streams
     const bool streamTrace = use_stream_schedule(c);
-    const int pipesInUse = streamTrace ? 1 : c->pipelines;
+    const int pipesInUse = streamTrace ? 1 : std::min(c->pipelines, rs.nPipes);
 
     // what camera_origin() returns on the device: xf_apply(c2w, (0, 0, 0), 1) with the same operation order
     float co[4];
@@ -359,7 +422,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     int passIndex = 0;
     for (int s0 = p->spp_begin; s0 < p->spp_end; s0 += sppPass, ++passIndex) {
         const int k = passIndex % pipesInUse;
-        PathBuffers &pb = c->pb[k];
+        PathBuffers &pb = rs.pb[k];
         hipStream_t st = c->pipeStream[k];
         PassInfo ps;
         ps.nPix = (uint32_t)nPix;
@@ -371,21 +434,21 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
         ps.maxDepth = p->max_depth;
         ps.rrThreshold = p->rr_threshold;
         HIPCHK(c, hipMemsetAsync(pb.counts, 0, (size_t)(p->max_depth + 2) * RT_CNT_PER_BOUNCE * RT_CNT_STRIDE * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cam, ps, pb, c->dStats);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cam, ps, pb, rs.stats);
         for (int b = 0; b <= p->max_depth; ++b) {
             const int cur = b & 1;
             // camera rays share their origin and have no origin records
             auto originsOf = [&](int bounce) { return bounce == 0 ? (const float4 *)nullptr : (const float4 *)pb.rayA[cur]; };
-            EventPair *ep = next_event_pair(c);
+            EventPair *ep = rs.timeExtend ? next_event_pair(c) : nullptr;
             if (ep) HIPCHK(c, hipEventRecord(ep->a, st));
             if (streamTrace) {
                 auto kx = RT_PICK(k_extend_stream, c, stats);
                 hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, originsOf(b),
-                                   (const float4 *)pb.rayB[cur], pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats, camOrigin);
+                                   (const float4 *)pb.rayB[cur], pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], rs.stats, camOrigin);
             } else {
                 auto kx = RT_PICK(k_extend, c, stats);
                 hipLaunchKernelGGL(kx, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, originsOf(b), (const float4 *)pb.rayB[cur], pb.hit,
-                                   (const uint32_t *)&pb.counts[cnt_index(b, 0)], c->dStats, camOrigin);
+                                   (const uint32_t *)&pb.counts[cnt_index(b, 0)], rs.stats, camOrigin);
             }
             if (ep) HIPCHK(c, hipEventRecord(ep->b, st));
             auto ksh = c->hasSpheres ? (c->allLambert ? k_shade<MATSET_LAMBERT, true> : k_shade<MATSET_ANY, true>)
@@ -394,18 +457,18 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
             if (b < p->max_depth) {
                 if (streamTrace) {
                     auto ks = RT_PICK(k_shadow_stream, c, stats);
-                    hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, pb, b, c->dStats);
+                    hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, pb, b, rs.stats);
                 } else {
                     auto ks = RT_PICK(k_shadow, c, stats);
-                    hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
+                    hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, rs.stats);
                 }
                 auto kp = RT_PICK(k_probe, c, stats);
-                hipLaunchKernelGGL(kp, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, c->dStats);
+                hipLaunchKernelGGL(kp, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, rs.stats);
             }
         }
         // film accumulation is ordered across passes: pass i+1 adds its samples after pass i
         if (lastPipe >= 0 && lastPipe != k) HIPCHK(c, hipStreamWaitEvent(st, c->pipeFilmDone[lastPipe], 0));
-        hipLaunchKernelGGL(k_film_path, dim3(grid), dim3(RT_BLOCK), 0, st, cam, ps, pb, rgb, wsum, c->dSpillRgb, c->dSpillW);
+        hipLaunchKernelGGL(k_film_path, dim3(grid), dim3(RT_BLOCK), 0, st, cam, ps, pb, rgb, wsum, rs.spillRgb, rs.spillW);
         HIPCHK(c, hipEventRecord(c->pipeFilmDone[k], st));
         lastPipe = k;
         HIPCHK(c, hipGetLastError());
@@ -415,7 +478,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
         HIPCHK(c, hipEventRecord(c->mainReady, c->pipeStream[k]));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->mainReady, 0));
     }
-    hipLaunchKernelGGL(k_merge_spill, dim3(grid), dim3(RT_BLOCK), 0, c->stream, (size_t)cam.width * cam.height, rgb, wsum, c->dSpillRgb, c->dSpillW);
+    hipLaunchKernelGGL(k_merge_spill, dim3(grid), dim3(RT_BLOCK), 0, c->stream, (size_t)cam.width * cam.height, rgb, wsum, rs.spillRgb, rs.spillW);
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
@@ -440,12 +503,16 @@ int render_path_tile_stream(rt_context *c, const rt_render_params *p, float *rgb
     return RT_OK;
 }
 
-int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *wsum, const RenderScratch *fixed) {
     const CameraDev &cam = c->cam;
     const int sbW = cam.sb[2] - cam.sb[0], sbH = cam.sb[3] - cam.sb[1];
     if (sbW <= 0 || sbH <= 0 || p->spp_end == p->spp_begin) return RT_OK;
     int rc;
-    if ((rc = ensure_spill(c))) return rc;
+    if (fixed && p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM)
+        return fail(c, RT_ERR_UNSUPPORTED, "the reference tile stream needs per-tile buffers: not available without allocation");
+    if (!fixed && (rc = ensure_spill(c))) return rc;
+    float *spillRgb = fixed ? fixed->spillRgb : c->dSpillRgb, *spillW = fixed ? fixed->spillW : c->dSpillW;
+    unsigned long long *statsPtr = fixed ? fixed->stats : c->dStats;
     const bool stats = p->collect_stats != 0;
     const size_t lds = trace_lds_bytes(c);
     const uint32_t ntx = (uint32_t)(sbW + 15) / 16, nty = (uint32_t)(sbH + 15) / 16;
@@ -508,22 +575,42 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
     const int grid = (int)std::min<uint32_t>((nSlots + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)c->gridBlocks * 4u);
     auto k = RT_PICK(k_whitted, c, stats);
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, c->sc, cam, p->spp_begin, p->spp_end, p->spp_total, p->max_depth, p->rng_mode,
-                       p->seed, (const uint2 *)c->dPixelState, rgb, wsum, c->dSpillRgb, c->dSpillW, c->dStats);
+                       p->seed, (const uint2 *)c->dPixelState, rgb, wsum, spillRgb, spillW, statsPtr);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_merge_spill, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, (size_t)cam.width * cam.height, rgb, wsum, c->dSpillRgb,
-                       c->dSpillW);
+    hipLaunchKernelGGL(k_merge_spill, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, (size_t)cam.width * cam.height, rgb, wsum, spillRgb,
+                       spillW);
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
 
-int render_dispatch(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+int render_dispatch(rt_context *c, const rt_render_params *p, float *rgb, float *wsum, const RenderScratch *fixed = nullptr) {
     int rc;
-    if (p->integrator == RT_INTEGRATOR_WHITTED) rc = render_whitted(c, p, rgb, wsum);
-    else rc = p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM ? render_path_tile_stream(c, p, rgb, wsum) : render_path(c, p, rgb, wsum);
+    if (p->integrator == RT_INTEGRATOR_WHITTED) rc = render_whitted(c, p, rgb, wsum, fixed);
+    else if (p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM)
+        rc = fixed ? fail(c, RT_ERR_UNSUPPORTED, "the reference tile stream is not available without allocation") : render_path_tile_stream(c, p, rgb, wsum);
+    else rc = render_path(c, p, rgb, wsum, fixed);
     // every renderer ends with k_merge_spill, which leaves the spill buffers zeroed; after an error return in between
     // they may hold samples of the failed render, and the next render clears them first (ensure_spill)
-    if (rc != RT_OK) c->spillDirty = true;
+    if (rc != RT_OK && !fixed) c->spillDirty = true;
     return rc;
+}
+
+// PathBuffers of one pipeline laid over the queue part of the scratch array: every per-path array holds `capacity` entries.
+PathBuffers carve_path_buffers(unsigned char *base, size_t capacity, uint32_t *counts) {
+    PathBuffers pb{};
+    float4 *q = reinterpret_cast<float4 *>(base);
+    auto take = [&](size_t vecPerPath) { float4 *r = q; q += capacity * vecPerPath; return r; };
+    for (int k = 0; k < 2; ++k) { pb.rayA[k] = take(1); pb.rayB[k] = take(1); }
+    pb.hit = take(1);
+    pb.L = take(1);
+    pb.beta = take(1);
+    pb.rng = reinterpret_cast<uint4 *>(take(1));
+    pb.shA = take(1);
+    pb.shB = take(1);
+    pb.shC = take(1);
+    pb.probe = take(6);
+    pb.counts = counts;
+    return pb;
 }
 
 }  // namespace
@@ -557,6 +644,7 @@ int rt_create(int device_id, rt_context **out) {
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->gridBlocks = c->numCUs * 8;
+    if ((e = scratch_address(device_id, &c->scratchPtr)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int k = 0; k < rt_context::kPipes; ++k) {
         if ((e = hipStreamCreateWithFlags(&c->pipeStream[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -763,6 +851,10 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     c->residentGrid.clear();
     sc.ldsSceneBytes = c->ldsScene ? (uint32_t)ldsBytes : 0;
     c->haveScene = true;
+    // resident grids of the streaming render stages, looked up now so that a render does not have to (the lookup fills a
+    // host-side table; rt_render_noalloc_dev allocates nothing, on the host side either)
+    (void)resident_grid(c, RT_PICK(k_extend_stream, c, false), stream_lds_bytes_of(c));
+    (void)resident_grid(c, RT_PICK(k_shadow_stream, c, false), stream_lds_bytes_of(c));
     return RT_OK;
 }
 
@@ -881,6 +973,32 @@ int rt_render_dev(rt_context *c, const rt_render_params *p, float *rgb, float *w
     if (!rgb || !wsum) return fail(c, RT_ERR_INVALID_ARG, "output buffers are NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return render_dispatch(c, p, rgb, wsum);
+}
+
+int rt_render_noalloc_dev(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    int rc = check_render_args(c, p);
+    if (rc) return rc;
+    if (!rgb || !wsum) return fail(c, RT_ERR_INVALID_ARG, "output buffers are NULL");
+    if (p->rng_mode != RT_RNG_COUNTER) return fail(c, RT_ERR_UNSUPPORTED, "rt_render_noalloc_dev: only RT_RNG_COUNTER (the tile stream needs per-tile buffers)");
+    if (p->collect_stats) return fail(c, RT_ERR_UNSUPPORTED, "rt_render_noalloc_dev: statistics are not collected");
+    if (p->max_depth > RT_NOALLOC_MAX_DEPTH) return fail(c, RT_ERR_UNSUPPORTED, "rt_render_noalloc_dev: max_depth above RT_NOALLOC_MAX_DEPTH");
+    const size_t filmPixels = (size_t)c->cam.width * c->cam.height;
+    const size_t samplePixels = (size_t)(c->cam.sb[2] - c->cam.sb[0]) * (size_t)(c->cam.sb[3] - c->cam.sb[1]);
+    if (filmPixels > noalloc::kMaxPaths || samplePixels > noalloc::kMaxPaths)
+        return fail(c, RT_ERR_UNSUPPORTED, "rt_render_noalloc_dev: film or sample bounds above RT_NOALLOC_MAX_PATHS pixels");
+    if (!c->scratchPtr) return fail(c, RT_ERR_HIP, "the scratch array has no address on this device");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned char *ptr = c->scratchPtr;   // the device address from hipGetSymbolAddress, never the array's name
+    // what must start at zero: the film spill buffers (samples that round onto a pixel border are staged there) and the
+    // statistics counters; the queue counters are cleared per pass by the renderer, the queues are written before read
+    HIPCHK(c, hipMemsetAsync(ptr + noalloc::kStatsOff, 0, noalloc::kCountsOff - noalloc::kStatsOff, c->stream));
+    HIPCHK(c, hipMemsetAsync(ptr + noalloc::kSpillRgbOff, 0, filmPixels * 3 * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(ptr + noalloc::kSpillWOff, 0, filmPixels * sizeof(float), c->stream));
+    PathBuffers pb = carve_path_buffers(ptr + noalloc::kQueuesOff, noalloc::kMaxPaths, reinterpret_cast<uint32_t *>(ptr + noalloc::kCountsOff));
+    const RenderScratch rs{&pb, 1, noalloc::kMaxPaths, reinterpret_cast<float *>(ptr + noalloc::kSpillRgbOff),
+                           reinterpret_cast<float *>(ptr + noalloc::kSpillWOff), reinterpret_cast<unsigned long long *>(ptr + noalloc::kStatsOff),
+                           false};
+    return render_dispatch(c, p, rgb, wsum, &rs);
 }
 
 int rt_render(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {

@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_version", "rt_upload_scene", "rt_set_camera", "rt_trace_closest",
     "rt_trace_any", "rt_trace_closest_dev", "rt_trace_any_dev", "rt_render", "rt_render_dev", "rt_synchronize", "rt_stream",
     "rt_get_stats", "rt_reset_stats", "rt_set_option", "rt_develop", "rt_develop_dev", "rt_set_film",
-    "rt_debug_sincos_disk", "rt_debug_sincos_cr", "rt_debug_whitted_passes",
+    "rt_debug_sincos_disk", "rt_debug_sincos_cr", "rt_debug_whitted_passes", "rt_render_noalloc_dev",
 ]
 
 
@@ -69,6 +69,7 @@ def device_lib():
         lib.rt_trace_any_dev.argtypes = [vp, u64, vp, vp, vp, vp]
         lib.rt_render.argtypes = [vp, C.POINTER(RtRenderParams), vp, vp]
         lib.rt_render_dev.argtypes = [vp, C.POINTER(RtRenderParams), vp, vp]
+        lib.rt_render_noalloc_dev.argtypes = [vp, C.POINTER(RtRenderParams), vp, vp]
         lib.rt_synchronize.argtypes = [vp]
         lib.rt_stream.argtypes = [vp]
         lib.rt_stream.restype = vp
@@ -200,6 +201,12 @@ class Context:
                          kw.get("spp_begin", 0), kw.get("spp_end"), kw.get("spp_per_pass", 0), kw.get("collect_stats", False),
                          kw.get("rr_threshold", 1.0))
         self._check(self._lib.rt_render_dev(self._h, C.byref(p), rgb_ptr, weight_ptr))
+
+    def render_noalloc_dev(self, rgb_ptr, weight_ptr, **kw):
+        """render_dev through the entry point that allocates nothing (queues in the library's static scratch array)."""
+        p = self._params(kw.get("integrator"), kw.get("spp"), kw.get("max_depth"), kw.get("rng_mode"), kw.get("seed", 0),
+                         kw.get("spp_begin", 0), kw.get("spp_end"), kw.get("spp_per_pass", 0), False, kw.get("rr_threshold", 1.0))
+        self._check(self._lib.rt_render_noalloc_dev(self._h, C.byref(p), rgb_ptr, weight_ptr))
 
     def set_trace_schedule(self, schedule):
         """Ray-to-lane schedule: "auto" (default), "lockstep" (one ray per lane) or "stream" (lanes take new rays as they finish)."""
