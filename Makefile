@@ -2,6 +2,7 @@
 #   raytracing_amd/lib/librt_host.so         host scene front-end (g++)
 #   raytracing_amd/lib/libraytracing_amd.so  HIP kernels + C ABI for gfx950 (hipcc)
 #   oracle/liboracle.so                      CPU restatement used by tests / bench cpu_baseline (g++)
+# and tests/bin/abi_harness, a plain C caller of the device library's ABI (gcc) that the GPU tests run as a process.
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
@@ -14,10 +15,11 @@ DEV_HDR = $(wildcard raytracing_amd/csrc/device/*.h) $(wildcard include/*.h)
 ORACLE_SRC = $(wildcard oracle/*.cpp)
 ORACLE_HDR = $(wildcard oracle/*.h) $(wildcard include/*.h)
 
-all: host device oracle
+all: host device oracle harness
 host: raytracing_amd/lib/librt_host.so
 device: raytracing_amd/lib/libraytracing_amd.so
 oracle: oracle/liboracle.so
+harness: tests/bin/abi_harness
 
 raytracing_amd/lib/librt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p raytracing_amd/lib
@@ -30,7 +32,12 @@ raytracing_amd/lib/libraytracing_amd.so: $(DEV_SRC) $(DEV_HDR)
 oracle/liboracle.so: $(ORACLE_SRC) $(ORACLE_HDR)
 	$(CXX) $(CXXFLAGS) -pthread -shared -o $@ $(ORACLE_SRC)
 
-clean:
-	rm -f raytracing_amd/lib/*.so oracle/liboracle.so
+tests/bin/abi_harness: tests/abi_harness.c include/raytracing_amd.h raytracing_amd/lib/libraytracing_amd.so
+	@mkdir -p tests/bin
+	gcc -std=c99 -O2 -Wall -Iinclude -o $@ tests/abi_harness.c -Lraytracing_amd/lib -lraytracing_amd \
+	    -Wl,-rpath,'$$ORIGIN/../../raytracing_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
-.PHONY: all host device oracle clean
+clean:
+	rm -f raytracing_amd/lib/*.so oracle/liboracle.so tests/bin/abi_harness
+
+.PHONY: all host device oracle harness clean

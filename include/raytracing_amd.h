@@ -10,8 +10,8 @@
  * Conventions: every entry point returns 0 on success or a negative rt_status, never throws or
  * aborts. Unless a name ends in _dev, pointers are HOST memory owned by the caller; the library
  * copies what it needs before returning. *_dev entry points take DEVICE pointers on the context's
- * GPU (for callers that keep rays / film buffers resident in HBM). One context per GPU per
- * process; a context is single-caller (not thread-safe), like the reference's render loop
+ * GPU (for callers that keep rays / film buffers resident in HBM). One context per GPU (rt_create) or per
+ * group of GPUs (rt_create_multi); a context is single-caller (not thread-safe), like the reference's render loop
  * (src/RayTracing.cpp:32-33).
  */
 #ifndef RAYTRACING_AMD_H
@@ -151,6 +151,24 @@ typedef struct rt_stats {
 /* Creates a context on HIP device `device_id`. Fails with RT_ERR_NO_DEVICE when no GPU is visible:
  * there is no CPU fallback. */
 int rt_create(int device_id, rt_context **out_ctx);
+/* One context over several GPUs of this node: the C++ host's whole-node drop-in for Renderer::render (reference
+ * src/core/Render/Render.h:20-21 is called once from main, src/RayTracing.cpp:32-33; the reference itself has no
+ * multi-device code). The context owns one sub-context per listed device and the RCCL communicator between them.
+ * rt_upload_scene, rt_set_camera, rt_set_film and rt_set_option address every device (the scene is replicated).
+ * rt_render / rt_render_dev split [spp_begin, spp_end) by sample index - device k of G renders
+ * [b + k (e - b) / G, b + (k + 1) (e - b) / G) of every pixel - and sum the per-device float films into device 0's with
+ * ONE ncclReduce (sum, fp32) over a packed buffer of 4 * width * height floats before adding them to the caller's
+ * buffers (device pointers of the *_dev variants live on device_ids[0]). Jobs that cannot be cut by sample index (the
+ * reference's tile stream) and the batch tracing, film development and no-allocation entry points run on device 0.
+ * RCCL (librccl.so) is opened at run time and only when n_devices > 1; n_devices == 1 is rt_create. Listing one device
+ * more than once is a one-GPU rehearsal of the same code path: RCCL refuses duplicate devices, so the films are then
+ * summed by a device-local kernel in member order. rt_get_stats sums the counters over the devices. */
+int rt_create_multi(const int *device_ids, int n_devices, rt_context **out_ctx);
+int rt_device_count(const rt_context *ctx);   /* devices of the context (1 for rt_create) */
+/* The sample-index range member `member` of `n_members` renders of a job [spp_begin, spp_end): contiguous, balanced to
+ * within one sample, the union over the members is the job. Host arithmetic only (no GPU needed); rt_render uses it, and
+ * a caller that runs one process per GPU (one rt_create each) uses it to pick each process's spp_begin / spp_end. */
+void rt_shard_range(int spp_begin, int spp_end, int member, int n_members, int *out_begin, int *out_end);
 void rt_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);   /* ctx may be NULL: last creation error */
 const char *rt_version(void);

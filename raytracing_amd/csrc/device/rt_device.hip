@@ -1,5 +1,7 @@
 // C ABI of the device library (include/raytracing_amd.h): context, scene upload, batch tracing, rendering.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the library is opened at run time by rt_create_multi (dlopen), never linked
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -118,6 +120,15 @@ struct rt_context {
     // film spill + whitted state
     float *dSpillRgb = nullptr, *dSpillW = nullptr;
     size_t spillPixels = 0;
+    // multi-GPU group (rt_create_multi): this context is the group's device 0, `peers` are the other devices'
+    // contexts. Scene, camera, film and options are mirrored to every member; a render is split by sample index and
+    // the members' films are summed into this device's with one RCCL reduce.
+    std::vector<rt_context *> peers;
+    rt_context *groupRoot = nullptr;        // set in a peer: the context that owns it
+    std::vector<ncclComm_t> comms;          // one per member, in member order; empty when the members share one GPU
+    float *dGroupFilm = nullptr;            // packed film of this member: rgb sums (3 n) then weight sums (n)
+    size_t groupFilmPixels = 0;
+    hipEvent_t groupDone = nullptr;
     unsigned char *scratchPtr = nullptr;   // this GPU's copy of the static scratch array (rt_render_noalloc_dev)
     bool spillDirty = false;   // the last render returned an error: the spill buffers may hold its samples
     uint2 *dPixelState = nullptr;
@@ -531,6 +542,8 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
         if (c->whittedScanCap < nSlotsPre) {
             if (c->dWhittedOffsets) (void)hipFree(c->dWhittedOffsets);
             if (c->dWhittedDraws) (void)hipFree(c->dWhittedDraws);
+    if (c->dGroupFilm) (void)hipFree(c->dGroupFilm);
+    if (c->groupDone) (void)hipEventDestroy(c->groupDone);
             c->dWhittedOffsets = c->dWhittedDraws = nullptr;
             c->whittedScanCap = 0;
             HIPCHK(c, hipMalloc((void **)&c->dWhittedOffsets, nSlotsPre * sizeof(unsigned long long) + 256 + (size_t)nTiles * sizeof(uint32_t)));
@@ -613,6 +626,130 @@ PathBuffers carve_path_buffers(unsigned char *base, size_t capacity, uint32_t *c
     return pb;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU group: samples-per-pixel split across the members, one RCCL sum-reduce of the packed float film
+// ---------------------------------------------------------------------------------------------------
+// RCCL is opened at run time, and only by rt_create_multi with more than one distinct device: a single-GPU process
+// never loads it. A copy already in the process (a host that brought its own) is preferred over the system's.
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rcclMutex;
+
+bool load_rccl(std::string &why) {
+    std::lock_guard<std::mutex> lock(g_rcclMutex);
+    if (g_rccl.handle) return true;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so"})
+        if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { why = std::string("cannot open librccl: ") + dlerror(); return false; }
+    RcclApi a;
+    a.handle = h;
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.Reduce = reinterpret_cast<decltype(a.Reduce)>(dlsym(h, "ncclReduce"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.CommInitAll || !a.CommDestroy || !a.Reduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
+        why = "librccl lacks a required entry point";
+        return false;
+    }
+    g_rccl = a;
+    return true;
+}
+
+#define NCCLCHK(ctx, expr)                                                                        \
+    do {                                                                                          \
+        ncclResult_t r_ = (expr);                                                                 \
+        if (r_ != ncclSuccess) {                                                                  \
+            (ctx)->err = std::string(#expr) + ": " + g_rccl.GetErrorString(r_);                   \
+            return RT_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+int ensure_group_film(rt_context *m, size_t nPix) {
+    if (m->groupFilmPixels == nPix && m->dGroupFilm) return RT_OK;
+    if (m->dGroupFilm) (void)hipFree(m->dGroupFilm);
+    m->dGroupFilm = nullptr;
+    m->groupFilmPixels = 0;
+    HIPCHK(m, hipMalloc((void **)&m->dGroupFilm, nPix * 4 * sizeof(float)));
+    m->groupFilmPixels = nPix;
+    return RT_OK;
+}
+
+// dst += src over n floats
+__global__ __launch_bounds__(RT_BLOCK) void k_add_floats(size_t n, float *__restrict__ dst, const float *__restrict__ src) {
+    for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RT_BLOCK) dst[i] += src[i];
+}
+
+// Render of a group. Member k of G renders sample indices [b + k (e - b) / G, b + (k + 1) (e - b) / G) of every pixel into
+// its own zeroed packed film on its own GPU; the films are summed into member 0's with ONE ncclReduce over 4 W H floats
+// (members on distinct GPUs) and added to the caller's buffers on device 0. The reference's per-tile random stream is
+// serial inside a tile and cannot be cut by sample index: such jobs run on member 0 alone.
+int render_group(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    const int G = 1 + (int)c->peers.size();
+    const int total = p->spp_end - p->spp_begin;
+    if (p->rng_mode == RT_RNG_REFERENCE_TILE_STREAM || total < G) return render_dispatch(c, p, rgb, wsum);
+    const size_t nPix = (size_t)c->cam.width * c->cam.height;
+    std::vector<rt_context *> members{c};
+    members.insert(members.end(), c->peers.begin(), c->peers.end());
+    int rc;
+    for (int k = 0; k < G; ++k) {
+        rt_context *m = members[k];
+        HIPCHK(c, hipSetDevice(m->device));
+        if ((rc = ensure_group_film(m, nPix))) { c->err = m->err; return rc; }
+        HIPCHK(c, hipMemsetAsync(m->dGroupFilm, 0, nPix * 4 * sizeof(float), m->stream));
+        rt_render_params pk = *p;
+        rt_shard_range(p->spp_begin, p->spp_end, k, G, &pk.spp_begin, &pk.spp_end);
+        if ((rc = render_dispatch(m, &pk, m->dGroupFilm, m->dGroupFilm + 3 * nPix))) { c->err = m->err; return rc; }
+    }
+    if (!c->comms.empty()) {
+        // distinct GPUs: every member's stream continues with its part of the collective, after its own render
+        NCCLCHK(c, g_rccl.GroupStart());
+        for (int k = 0; k < G; ++k) {
+            rt_context *m = members[k];
+            HIPCHK(c, hipSetDevice(m->device));
+            NCCLCHK(c, g_rccl.Reduce(m->dGroupFilm, m->dGroupFilm, nPix * 4, ncclFloat, ncclSum, 0, c->comms[k], m->stream));
+        }
+        NCCLCHK(c, g_rccl.GroupEnd());
+        HIPCHK(c, hipSetDevice(c->device));
+    } else {
+        // rehearsal on one GPU (the same device listed more than once; RCCL refuses that): device-local sums in member order
+        HIPCHK(c, hipSetDevice(c->device));
+        for (int k = 1; k < G; ++k) {
+            rt_context *m = members[k];
+            HIPCHK(c, hipEventRecord(m->groupDone, m->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, m->groupDone, 0));
+            hipLaunchKernelGGL(k_add_floats, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, nPix * 4, c->dGroupFilm, (const float *)m->dGroupFilm);
+        }
+    }
+    hipLaunchKernelGGL(k_add_floats, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, nPix * 3, rgb, (const float *)c->dGroupFilm);
+    hipLaunchKernelGGL(k_add_floats, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, nPix, wsum, (const float *)(c->dGroupFilm + 3 * nPix));
+    HIPCHK(c, hipGetLastError());
+    // the peers' streams are drained before the call returns: their next render reuses the packed films
+    for (int k = 1; k < G; ++k) {
+        HIPCHK(c, hipSetDevice(members[k]->device));
+        HIPCHK(c, hipStreamSynchronize(members[k]->stream));
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    return RT_OK;
+}
+
+int render_any(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
+    return c->peers.empty() ? render_dispatch(c, p, rgb, wsum) : render_group(c, p, rgb, wsum);
+}
+
 }  // namespace
 
 extern "C" {
@@ -657,7 +794,7 @@ int rt_create(int device_id, rt_context **out) {
     return RT_OK;
 }
 
-void rt_destroy(rt_context *c) {
+static void destroy_one(rt_context *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -679,7 +816,7 @@ void rt_destroy(rt_context *c) {
     delete c;
 }
 
-int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
+static int upload_scene_one(rt_context *c, const rt_scene_desc *d) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (!d || !d->nodes || !d->tri_p || !d->material_id || !d->light_id || !d->materials || d->n_nodes == 0 || d->n_prims == 0 ||
         d->n_materials == 0 || (d->n_leaf_idx && !d->leaf_idx) || (d->n_lights && !d->lights))
@@ -858,7 +995,7 @@ int rt_upload_scene(rt_context *c, const rt_scene_desc *d) {
     return RT_OK;
 }
 
-int rt_set_camera(rt_context *c, const float r2c[16], const float c2w[16], int width, int height, const int sb[4]) {
+static int set_camera_one(rt_context *c, const float r2c[16], const float c2w[16], int width, int height, const int sb[4]) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (!r2c || !c2w || !sb || width <= 0 || height <= 0) return fail(c, RT_ERR_INVALID_ARG, "bad camera argument");
     // Film::getSampleBounds reaches past the film by ceil(radius - 0.5) pixels (Object/Film.cpp:79-85)
@@ -882,7 +1019,7 @@ int rt_set_camera(rt_context *c, const float r2c[16], const float c2w[16], int w
     return RT_OK;
 }
 
-int rt_set_film(rt_context *c, float radius_x, float radius_y, const int cb[4], float max_sample_luminance) {
+static int set_film_one(rt_context *c, float radius_x, float radius_y, const int cb[4], float max_sample_luminance) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (!c->haveCamera) return fail(c, RT_ERR_NO_CAMERA, "rt_set_film follows rt_set_camera");
     if (!cb || !(radius_x > 0) || !(radius_y > 0) || radius_x > 32.f || radius_y > 32.f) return fail(c, RT_ERR_INVALID_ARG, "bad film argument");
@@ -972,7 +1109,7 @@ int rt_render_dev(rt_context *c, const rt_render_params *p, float *rgb, float *w
     if (rc) return rc;
     if (!rgb || !wsum) return fail(c, RT_ERR_INVALID_ARG, "output buffers are NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    return render_dispatch(c, p, rgb, wsum);
+    return render_any(c, p, rgb, wsum);
 }
 
 int rt_render_noalloc_dev(rt_context *c, const rt_render_params *p, float *rgb, float *wsum) {
@@ -1014,7 +1151,7 @@ int rt_render(rt_context *c, const rt_render_params *p, float *rgb, float *wsum)
     CK(hipMemcpy(dRgb, rgb, n * 12, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, wsum, n * 4, hipMemcpyHostToDevice));
     const auto t0 = std::chrono::steady_clock::now();
-    rc = render_dispatch(c, p, dRgb, dW);
+    rc = render_any(c, p, dRgb, dW);
     if (rc == RT_OK) {
         CK(hipStreamSynchronize(c->stream));
         c->renderMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1026,7 +1163,7 @@ int rt_render(rt_context *c, const rt_render_params *p, float *rgb, float *wsum)
 }
 #undef CK
 
-int rt_synchronize(rt_context *c) {
+static int synchronize_one(rt_context *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1073,7 +1210,7 @@ int rt_develop(rt_context *c, const float *rgb, const float *wsum, float film_sc
     return rc;
 }
 
-int rt_set_option(rt_context *c, int option, int value) {
+static int set_option_one(rt_context *c, int option, int value) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (option == RT_OPTION_TRACE_SCHEDULE) {
         if (value != RT_SCHEDULE_AUTO && value != RT_SCHEDULE_LOCKSTEP && value != RT_SCHEDULE_STREAM) return fail(c, RT_ERR_INVALID_ARG, "unknown trace schedule");
@@ -1088,7 +1225,7 @@ int rt_set_option(rt_context *c, int option, int value) {
     return fail(c, RT_ERR_INVALID_ARG, "unknown option");
 }
 
-int rt_get_stats(rt_context *c, rt_stats *out) {
+static int get_stats_one(rt_context *c, rt_stats *out) {
     if (!c || !out) return RT_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1119,7 +1256,7 @@ int rt_get_stats(rt_context *c, rt_stats *out) {
     return RT_OK;
 }
 
-int rt_reset_stats(rt_context *c) {
+static int reset_stats_one(rt_context *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1135,5 +1272,115 @@ int rt_reset_stats(rt_context *c) {
 void rt_debug_sincos_disk(float theta, float *s, float *c) { sincos_disk(theta, *s, *c); }
 int rt_debug_whitted_passes(const rt_context *c) { return c ? c->whittedPasses : 0; }
 void rt_debug_sincos_cr(float theta, float *s, float *c) { sincos_cr(theta, *s, *c); }
+
+
+// ---- entry points that address every member of a group ------------------------------------------------------------
+
+int rt_create_multi(const int *device_ids, int n_devices, rt_context **out) {
+    if (!out) { g_create_err = "out_ctx is NULL"; return RT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > noalloc::kMaxDevices) { g_create_err = "bad device list"; return RT_ERR_INVALID_ARG; }
+    rt_context *root = nullptr;
+    int rc = rt_create(device_ids[0], &root);
+    if (rc) return rc;
+    bool distinct = true;
+    for (int k = 0; k < n_devices; ++k)
+        for (int j = 0; j < k; ++j)
+            if (device_ids[k] == device_ids[j]) distinct = false;
+    for (int k = 1; k < n_devices; ++k) {
+        rt_context *m = nullptr;
+        if ((rc = rt_create(device_ids[k], &m))) { rt_destroy(root); return rc; }
+        m->groupRoot = root;
+        root->peers.push_back(m);
+    }
+    if (n_devices == 1) { *out = root; return RT_OK; }
+    std::vector<rt_context *> members{root};
+    members.insert(members.end(), root->peers.begin(), root->peers.end());
+    for (rt_context *m : members) {
+        hipError_t e = hipSetDevice(m->device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->groupDone, hipEventDisableTiming);
+        if (e != hipSuccess) { g_create_err = std::string("hipEventCreate: ") + hipGetErrorString(e); rt_destroy(root); return RT_ERR_HIP; }
+    }
+    if (distinct) {
+        std::string why;
+        if (!load_rccl(why)) { g_create_err = why; rt_destroy(root); return RT_ERR_UNSUPPORTED; }
+        root->comms.assign(n_devices, nullptr);
+        const ncclResult_t r = g_rccl.CommInitAll(root->comms.data(), n_devices, device_ids);
+        if (r != ncclSuccess) {
+            g_create_err = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r);
+            root->comms.clear();
+            rt_destroy(root);
+            return RT_ERR_HIP;
+        }
+    }
+    (void)hipSetDevice(root->device);
+    *out = root;
+    return RT_OK;
+}
+
+void rt_shard_range(int spp_begin, int spp_end, int member, int n_members, int *out_begin, int *out_end) {
+    const long long total = (long long)spp_end - spp_begin;
+    *out_begin = spp_begin + (int)(member * total / n_members);
+    *out_end = spp_begin + (int)((member + 1) * total / n_members);
+}
+
+int rt_device_count(const rt_context *c) { return c ? 1 + (int)c->peers.size() : 0; }
+
+void rt_destroy(rt_context *c) {
+    if (!c) return;
+    for (rt_context *m : c->peers) {
+        (void)hipSetDevice(m->device);
+        if (m->stream) (void)hipStreamSynchronize(m->stream);
+    }
+    for (ncclComm_t comm : c->comms)
+        if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+    c->comms.clear();
+    for (rt_context *m : c->peers) destroy_one(m);
+    c->peers.clear();
+    destroy_one(c);
+}
+
+#define FOR_EACH_MEMBER(c, call)                                                        \
+    do {                                                                                \
+        if (!(c)) return RT_ERR_INVALID_ARG;                                            \
+        rt_context *m = (c);                                                            \
+        int rc_ = (call);                                                               \
+        if (rc_) return rc_;                                                            \
+        for (rt_context *peer_ : (c)->peers) {                                          \
+            m = peer_;                                                                  \
+            rc_ = (call);                                                               \
+            if (rc_) { (c)->err = m->err; (void)hipSetDevice((c)->device); return rc_; }\
+        }                                                                               \
+        if (!(c)->peers.empty()) (void)hipSetDevice((c)->device);                       \
+        return RT_OK;                                                                   \
+    } while (0)
+
+int rt_upload_scene(rt_context *c, const rt_scene_desc *d) { FOR_EACH_MEMBER(c, upload_scene_one(m, d)); }
+int rt_set_camera(rt_context *c, const float r2c[16], const float c2w[16], int width, int height, const int sb[4]) {
+    FOR_EACH_MEMBER(c, set_camera_one(m, r2c, c2w, width, height, sb));
+}
+int rt_set_film(rt_context *c, float radius_x, float radius_y, const int cb[4], float max_sample_luminance) {
+    FOR_EACH_MEMBER(c, set_film_one(m, radius_x, radius_y, cb, max_sample_luminance));
+}
+int rt_set_option(rt_context *c, int option, int value) { FOR_EACH_MEMBER(c, set_option_one(m, option, value)); }
+int rt_reset_stats(rt_context *c) { FOR_EACH_MEMBER(c, reset_stats_one(m)); }
+int rt_synchronize(rt_context *c) { FOR_EACH_MEMBER(c, synchronize_one(m)); }
+
+// Counters are summed over the members; times and the state fields are member 0's.
+int rt_get_stats(rt_context *c, rt_stats *out) {
+    if (!c || !out) return RT_ERR_INVALID_ARG;
+    int rc = get_stats_one(c, out);
+    for (rt_context *m : c->peers) {
+        rt_stats s;
+        if (rc == RT_OK && (rc = get_stats_one(m, &s)) == RT_OK) {
+            out->rays_closest += s.rays_closest; out->rays_any += s.rays_any; out->camera_samples += s.camera_samples;
+            out->n_interior += s.n_interior; out->n_leaf += s.n_leaf; out->n_leaf_idx += s.n_leaf_idx; out->n_tri_tests += s.n_tri_tests;
+            out->counted_rays += s.counted_rays; out->extend_launches += s.extend_launches; out->extend_rays += s.extend_rays;
+            out->extend_ms += s.extend_ms;
+        } else if (rc) c->err = m->err;
+    }
+    if (!c->peers.empty()) (void)hipSetDevice(c->device);
+    return rc;
+}
 
 }  // extern "C"

@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_version", "rt_upload_scene", "rt_set_camera", "rt_trace_closest",
     "rt_trace_any", "rt_trace_closest_dev", "rt_trace_any_dev", "rt_render", "rt_render_dev", "rt_synchronize", "rt_stream",
     "rt_get_stats", "rt_reset_stats", "rt_set_option", "rt_develop", "rt_develop_dev", "rt_set_film",
-    "rt_debug_sincos_disk", "rt_debug_sincos_cr", "rt_debug_whitted_passes", "rt_render_noalloc_dev",
+    "rt_debug_sincos_disk", "rt_debug_sincos_cr", "rt_debug_whitted_passes", "rt_render_noalloc_dev", "rt_create_multi", "rt_device_count", "rt_shard_range",
 ]
 
 
@@ -55,6 +55,10 @@ def device_lib():
         lib = C.CDLL(path)
         vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
         lib.rt_create.argtypes = [i32, C.POINTER(vp)]
+        lib.rt_create_multi.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+        lib.rt_device_count.argtypes = [vp]
+        lib.rt_shard_range.argtypes = [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+        lib.rt_shard_range.restype = None
         lib.rt_destroy.argtypes = [vp]
         lib.rt_destroy.restype = None
         lib.rt_last_error.argtypes = [vp]
@@ -87,12 +91,18 @@ class RtError(RuntimeError):
 
 
 class Context:
-    """One rt_context on one GPU."""
+    """One rt_context: on one GPU (device_id), or over several GPUs of the node (device_ids: rt_create_multi - renders are
+    split by sample index and summed over RCCL inside the library; device pointers belong to device_ids[0])."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, device_ids=None):
         self._lib = device_lib()
         h = C.c_void_p()
-        rc = self._lib.rt_create(int(device_id), C.byref(h))
+        if device_ids is None:
+            rc = self._lib.rt_create(int(device_id), C.byref(h))
+        else:
+            ids = (C.c_int * len(device_ids))(*[int(v) for v in device_ids])
+            rc = self._lib.rt_create_multi(ids, len(device_ids), C.byref(h))
+            device_id = int(device_ids[0])
         if rc != 0:
             raise RtError(f"rt_create failed ({rc}): {self._lib.rt_last_error(None).decode()}")
         self._h = h
@@ -227,6 +237,9 @@ class Context:
 
     def develop_dev(self, rgb_ptr, weight_ptr, out_ptr, film_scale=1.0):
         self._check(self._lib.rt_develop_dev(self._h, rgb_ptr, weight_ptr, float(film_scale), out_ptr))
+
+    def device_count(self):
+        return self._lib.rt_device_count(self._h)
 
     def synchronize(self):
         self._check(self._lib.rt_synchronize(self._h))

@@ -13,7 +13,13 @@ def shard_range(spp_total, rank, world_size):
     """Contiguous, balanced sample-index range [begin, end) of `rank`."""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
-    return (rank * spp_total) // world_size, ((rank + 1) * spp_total) // world_size
+    # the library's own rule (rt_shard_range), so that one process per GPU and one context over several GPUs
+    # (rt_create_multi) cut a job at the same sample indices
+    import ctypes as C
+    from .device import device_lib
+    b, e = C.c_int(), C.c_int()
+    device_lib().rt_shard_range(0, int(spp_total), int(rank), int(world_size), C.byref(b), C.byref(e))
+    return b.value, e.value
 
 
 def reduce_film(rgb, weight, dst=0):

@@ -100,3 +100,46 @@ def test_device_trig_helpers_are_correctly_rounded():
             fn(float(t), C.byref(s), C.byref(c))
             bad += (np.float32(np.sin(np.float64(t))) != np.float32(s.value)) + (np.float32(np.cos(np.float64(t))) != np.float32(c.value))
         assert bad == 0, f"{name}: {bad} results differ from the correctly rounded value"
+
+
+def test_shard_rule_covers_every_job_exactly_once():
+    """rt_shard_range (the split rt_render applies inside a multi-GPU context, host arithmetic only): contiguous shards
+    in member order, union = the job, sizes balanced to within one sample, also when there are fewer samples than
+    members or the job does not start at sample 0."""
+    from raytracing_amd.device import device_lib
+    from raytracing_amd.distributed import shard_range
+    lib = device_lib()
+    b, e = C.c_int(), C.c_int()
+    for begin, end in ((0, 1024), (0, 7), (3, 3), (5, 1000), (0, 1), (17, 20)):
+        for g in (1, 2, 3, 4, 8, 64):
+            at = begin
+            sizes = []
+            for k in range(g):
+                lib.rt_shard_range(begin, end, k, g, C.byref(b), C.byref(e))
+                assert b.value == at and e.value >= b.value
+                sizes.append(e.value - b.value)
+                at = e.value
+            assert at == end and max(sizes) - min(sizes) <= 1
+    assert [shard_range(1024, k, 8) for k in range(8)] == [(128 * k, 128 * (k + 1)) for k in range(8)]
+    assert [shard_range(10, k, 4) for k in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
+
+
+def test_rccl_offers_what_the_multi_gpu_context_binds():
+    """rt_create_multi opens librccl at run time (the device library does not link it): the entry points it looks up must
+    exist in the RCCL of this image, and the device library must not depend on RCCL at load time."""
+    import subprocess
+    from raytracing_amd.device import device_lib
+    device_lib()
+    path = os.path.join(ROOT, "raytracing_amd", "lib", "libraytracing_amd.so")
+    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed.lower()
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    assert rccl is not None, "no librccl on this machine"
+    for sym in ("ncclCommInitAll", "ncclCommDestroy", "ncclReduce", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert getattr(rccl, sym) is not None

@@ -36,6 +36,10 @@ def main():
 
 
 def measure(scene, cfg, label, n, reps, depth):
+    # RT_HBM_WHAT: comma list of primary, incoherent, path (default: all); RT_HBM_SCHEDULES: lockstep, stream (default: both).
+    # Profiler runs name one of each so that the counters belong to one kernel on one workload.
+    what = set(os.environ.get("RT_HBM_WHAT", "primary,incoherent,path").split(","))
+    schedules = os.environ.get("RT_HBM_SCHEDULES", "lockstep,stream").split(",")
     ctx = Context(0)
     ctx.upload_scene(scene)
     dev = torch.device("cuda", 0)
@@ -65,7 +69,7 @@ def measure(scene, cfg, label, n, reps, depth):
         d = torch.tensor(d_np, device=dev)
         out = {"workload": f"{label}, {name} rays", "n_rays": n,
                "per_ray": {"interior": ni, "leaf": nl, "leaf_idx": nidx, "tri_tests": ntri}, "bytes_per_ray": bpr}
-        for stream in (False, True):
+        for stream in [sch == "stream" for sch in schedules]:
             ctx.set_trace_schedule("stream" if stream else "lockstep")
             dt = timed(lambda: ctx.trace_closest_dev(n, o.data_ptr(), d.data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr()))
             key = "stream" if stream else "lockstep"
@@ -87,15 +91,20 @@ def measure(scene, cfg, label, n, reps, depth):
     if len(d) < n:
         d = np.concatenate([d, d[: n - len(d)]])
     o = np.broadcast_to(eye, d.shape).copy()
-    run("primary", o, d.astype(np.float32))
-    o, d = raygen.incoherent_rays(scene.bounds, n, 3)
-    run("incoherent", o, d)
+    if "primary" in what:
+        run("primary", o, d.astype(np.float32))
+    if "incoherent" in what:
+        o, d = raygen.incoherent_rays(scene.bounds, n, 3)
+        run("incoherent", o, d)
+    if "path" not in what:
+        ctx.close()
+        return
 
     # path tracing (PathRenderer::Li) at 1920x1080, 16 spp
     ctx.set_camera(cfg)
     rgb = torch.zeros((cfg.height, cfg.width, 3), dtype=torch.float32, device=dev)
     w = torch.zeros((cfg.height, cfg.width), dtype=torch.float32, device=dev)
-    for schedule in ("lockstep", "stream"):
+    for schedule in schedules:
         ctx.set_trace_schedule(schedule)
         ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=16, max_depth=depth)
         ctx.synchronize()
