@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path on MI355X: cornellBox PathTracing at 1920x1080 (BASELINE config 3).
+"""Benchmark of the hot path on MI355X: cornellBox PathTracing at 1920x1080 (BASELINE configs[2]).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One step = one wavefront pass of SPP_PER_STEP samples per pixel over the whole 1080p frame on every rank
 (raygen, then extend/shade/shadow/probe for each bounce up to depth 15, then the film accumulation). Rank g
-renders sample indices [g*K*P, (g+1)*K*P) of a (N*K*P)-spp job; after the K steps the float film is
-sum-reduced to rank 0 over RCCL inside the timed region. The scene is resident in HBM and camera rays are
-generated on the device, so no host data moves in the timed region.
+renders sample indices [g*K*P, (g+1)*K*P) of a (N*K*P)-spp job; after the K steps the float film (one packed buffer of
+4 W H floats) is sum-reduced to rank 0 over RCCL inside the timed region. The scene is resident in HBM and camera rays
+are generated on the device, so no host data moves in the timed region.
 
 Prints ONE JSON line (rank 0). value = whole-job Mrays/s, one ray = one KD-tree traversal of either flavour
-(extend + MIS-probe + shadow), counted by the kernels themselves.
+(extend + MIS-probe + shadow), counted by the kernels themselves. Besides the contract's fields the line carries
+  roofline        k_extend, the dominant traversal kernel, against the roof that binds it on this 8 KB scene (VALU issue),
+                  with its HBM side and its lane occupancy from the hardware counters
+  roofline_shade  k_shade against HBM
+  strong_1024spp  BASELINE configs[2] as worded: ONE 1024-spp job split over the N ranks, reduce included (after the
+                  weak-scaling region the driver times)
+  secondary       BASELINE configs[3], the 1 M-triangle soup whose tables live in HBM (1-GPU runs only): the
+                  incoherent-ray batch and a 1080p x 16 spp path trace, with the HBM roofline of the streaming traversal kernel
+  cpu_baseline    the CPU oracle on the host cores, on bounded samples of the same workloads
 """
 import argparse
 import json
@@ -27,13 +35,28 @@ import numpy as np  # noqa: E402
 WIDTH, HEIGHT = 1920, 1080
 SPP_PER_STEP = int(os.environ.get("RT_BENCH_SPP_PER_STEP", "32"))
 MAX_DEPTH = 15
+STRONG_SPP = 1024
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 FP32_VALU_PEAK_TFLOPS = 157.3
-# HBM-side bytes per ray of k_extend from the hardware counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes over this workload, profiles/r01_pmc_bench_steps4_v13.md): 2 x 13.5 B read (gfx950 counts the 16-B-per-lane
-# coalesced reads at half their bytes; camera rays have no origin record) + 17.0 B written. Counters cannot be read
-# inside a timed run, so the figure measured under the profiler is scaled by this run's rays per launch.
-EXTEND_HBM_BYTES_PER_RAY_PMC = 44.0
+# Figures that only the hardware counters give (rocprofv3 --pmc runs of this same command, summaries under profiles/);
+# counters cannot be read inside a timed run, so the per-ray figures measured under the profiler are scaled by this run's
+# own ray counts and HIP-event times.
+PMC = {
+    "source": "profiles/r01_pmc_bench_steps4_v13.md",
+    # HBM-side bytes per ray of k_extend: 2 x 13.5 B read (gfx950's FETCH_SIZE counts 16-B-per-lane coalesced reads at
+    # half their bytes; camera rays have no origin record) + 17.0 B written
+    "extend_hbm_bytes_per_ray": 44.0,
+    "extend_lanes_active": 12.5,            # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, of 64
+    "extend_lds_conflict_cycles": 0.39,     # SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS
+    "shade_hbm_bytes_per_path": 103.0,      # k_shade: (FETCH_SIZE x 2 + WRITE_SIZE) per ray entering the kernel
+    "shade_lanes_active": 54.0,
+}
+PMC_SOUP = {
+    "source": "profiles/r02_soup_base_pmc_incoherent.md",
+    "fetch_bytes_per_ray_raw": 3890.0,      # FETCH_SIZE per ray (64 B per request, no correction: 8-byte gathers)
+    "l2_hit_rate": 0.52,
+    "lanes_active": 18.3,
+}
 
 
 def bytes_per_ray(ni, nl, nidx, ntri, closest=True):
@@ -46,12 +69,23 @@ def flops_per_ray(ni, ntri, ncand):
     return 40 + 6 * ni + 44 * ntri + 35 * ncand
 
 
-def cpu_baseline(scene, cfg, target_seconds=15.0):
+# k_shade per ray entering it: the hit record (16 B) is read for every ray; a ray that hit (~85 % after bounce 0) reads
+# its direction record, throughput and generator state (48 B) and writes the next ray (32 B), throughput and generator
+# (32 B) and a shadow entry (48 B). Scene tables (80 B per primitive) stay in L2.
+SHADE_BYTES_PER_PATH = 16 + 0.85 * (48 + 32 + 32 + 48)
+
+
+def host_cores():
+    """Threads the CPU baseline uses: the job's share of the machine (OMP_NUM_THREADS on the GPU box), at most 16."""
+    return int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+
+
+def cpu_baseline(scene, cfg, target_seconds=12.0):
     """Times the CPU oracle (a port of the reference's path; the reference's sources cannot travel to this
-    machine) on all host cores given to this job, on a bounded sample of the same workload."""
+    machine) on the host cores given to this job, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores = host_cores()
     orc = Oracle(scene, cfg)
     _, _, st = orc.render(integrator=0, rng_mode=0, seed=1, spp=1, threads=cores)     # calibration pass
     rate = st["camera_samples"] / max(st["seconds"], 1e-9)
@@ -64,9 +98,120 @@ def cpu_baseline(scene, cfg, target_seconds=15.0):
         "samples_per_sec": st["camera_samples"] / st["seconds"],
         "seconds": st["seconds"],
         "cores": cores,
+        "host_cpu_count": os.cpu_count(),
         "kind": "port",
         "sample": f"cornellBox PathTracing {cfg.width}x{cfg.height}, depth {MAX_DEPTH}, {spp} spp (of the GPU job's), {cores} threads",
     }
+
+
+def soup_secondary(torch, dev, base_cfg, with_cpu):
+    """BASELINE configs[3]: 1 M-triangle soup (tables in HBM). Incoherent closest-hit batch with the library's default
+    schedule for such scenes, timed with HIP events on the library's own stream, and a 1080p x 16 spp path trace."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import raygen
+    from raytracing_amd.device import Context
+    n_tris, n_rays, reps = 1_000_000, 1 << 22, 5
+    t0 = time.perf_counter()
+    scene, cfg = raygen.soup_scene(n_tris, base_cfg)
+    build_s = time.perf_counter() - t0
+    ctx = Context(dev.index)
+    ctx.upload_scene(scene)
+    o_np, d_np = raygen.incoherent_rays(scene.bounds, n_rays, 3)
+    # per-ray work from the instrumented kernel on a sample of the batch
+    step = n_rays // 200_000
+    ctx.reset_stats()
+    ctx.trace_closest(np.ascontiguousarray(o_np[::step]), np.ascontiguousarray(d_np[::step]))
+    st = ctx.stats()
+    cr = max(1, st["counted_rays"])
+    ni, nl, nidx, ntri = st["n_interior"] / cr, st["n_leaf"] / cr, st["n_leaf_idx"] / cr, st["n_tri_tests"] / cr
+    bpr = bytes_per_ray(ni, nl, nidx, ntri)
+    o, d = torch.tensor(o_np, device=dev), torch.tensor(d_np, device=dev)
+    prim = torch.empty(n_rays, dtype=torch.int32, device=dev)
+    t = torch.empty(n_rays, dtype=torch.float32, device=dev)
+    bary = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.ExternalStream(ctx.stream(), device=dev)   # the stream the kernel is launched on
+
+    def launch():
+        ctx.trace_closest_dev(n_rays, o.data_ptr(), d.data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr())
+
+    launch()
+    ctx.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        launch()
+    e1.record(stream)
+    ctx.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    achieved = bpr * n_rays / (ms * 1e-3) / 1e9
+    out = {
+        "workload": f"{n_tris}-triangle soup (BASELINE configs[3]): {scene.n_nodes} KD nodes, {len(scene.leaf_idx)} leaf indices, "
+                    f"{(scene.n_nodes * 8 + len(scene.leaf_idx) * 4 + scene.n_prims * 48) / 1e6:.0f} MB of traversal tables in HBM",
+        "host_build_seconds": build_s,
+        "incoherent": {
+            "n_rays": n_rays,
+            "Mrays_per_s": n_rays / (ms * 1e-3) / 1e6,
+            "hit_fraction": float((prim >= 0).float().mean()),
+            "roofline": {
+                "kernel": "k_trace_closest_stream (the traversal of k_extend_stream on a caller's batch)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": PMC_SOUP["fetch_bytes_per_ray_raw"] * n_rays,
+                "traffic_unit": "bytes per launch fetched by L2 from the fabric (PMC FETCH_SIZE, uncorrected; includes Infinity Cache hits)",
+                "bytes_per_ray": bpr,
+                "avg_launch_ms": ms,
+                "launches": reps,
+                "per_ray": {"interior": ni, "leaf": nl, "leaf_idx": nidx, "tri_tests": ntri},
+                "l2_hit_rate_pmc": PMC_SOUP["l2_hit_rate"],
+                "lanes_active_pmc": PMC_SOUP["lanes_active"],
+                "pmc_source": PMC_SOUP["source"],
+            },
+        },
+    }
+    # path tracing on the same scene
+    ctx.set_camera(cfg)
+    rgb = torch.zeros((cfg.height, cfg.width, 3), dtype=torch.float32, device=dev)
+    w = torch.zeros((cfg.height, cfg.width), dtype=torch.float32, device=dev)
+    kw = dict(integrator=0, rng_mode=0, seed=1, spp=16, max_depth=MAX_DEPTH)
+    ctx.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)
+    ctx.synchronize()
+    rgb.zero_()
+    w.zero_()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    ctx.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    rays = st["rays_closest"] + st["rays_any"]
+    out["path_1080p_16spp"] = {"seconds": dt, "Mrays_per_s": rays / dt / 1e6, "samples_per_sec": st["camera_samples"] / dt,
+                               "rays_per_sample": rays / max(1, st["camera_samples"]),
+                               "extend_avg_launch_ms": st["extend_ms"] / max(1, st["extend_launches"])}
+    ctx.close()
+    if with_cpu:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle_lib import Oracle
+        cores = host_cores()
+        orc = Oracle(scene, cfg)
+        n_cpu = n_rays   # ~1.3 s on 16 threads, ~20 core-seconds
+        chunks = np.array_split(np.arange(n_cpu), cores)
+
+        def work(idx):
+            orc.trace_closest(o_np[idx], d_np[idx])
+
+        with ThreadPoolExecutor(cores) as pool:
+            list(pool.map(work, [c[:1000] for c in chunks]))   # touch the tables once
+            t0 = time.perf_counter()
+            list(pool.map(work, chunks))
+            cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n_cpu / cpu_s / 1e6, "unit": "Mrays/s", "seconds": cpu_s, "cores": cores,
+                               "host_cpu_count": os.cpu_count(), "kind": "port",
+                               "sample": f"the same {n_cpu} incoherent rays, closest hit, {cores} threads"}
+        out["incoherent"]["gpu_over_cpu"] = out["incoherent"]["Mrays_per_s"] / out["cpu_baseline"]["value"]
+    return out
 
 
 def main():
@@ -75,11 +220,14 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 1 M-triangle soup (BASELINE configs[3])")
+    ap.add_argument("--no-strong", action="store_true", help="skip the 1024-spp strong-scaling job")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from raytracing_amd.device import Context
+    from raytracing_amd.distributed import shard_range
     from raytracing_amd.scene import FlatScene
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,8 +268,11 @@ def main():
 
     K, W, P = args.steps, args.warmup, SPP_PER_STEP
     spp_total = world * K * P
-    rgb = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
-    wsum = torch.zeros((HEIGHT, WIDTH), dtype=torch.float32, device=dev)
+    # the film as ONE buffer - rgb sums (3 W H) then weight sums (W H) - so that the exchange step is one reduce
+    npix = WIDTH * HEIGHT
+    film = torch.zeros(4 * npix, dtype=torch.float32, device=dev)
+    rgb = film[:3 * npix].view(HEIGHT, WIDTH, 3)
+    wsum = film[3 * npix:].view(HEIGHT, WIDTH)
 
     def run(spp_begin, spp_end, total, collect=False):
         ctx.render_dev(rgb.data_ptr(), wsum.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=total, max_depth=MAX_DEPTH,
@@ -147,11 +298,9 @@ def main():
     if world > 1:
         # first use of the collectives (communicator set-up, channel buffers) belongs to the warm-up, not to the timed steps
         ctx.synchronize()
-        reduce_to_rank0(rgb)
-        reduce_to_rank0(wsum)
+        reduce_to_rank0(film)
     fence()
-    rgb.zero_()
-    wsum.zero_()
+    film.zero_()
     ctx.reset_stats()
     fence()
 
@@ -159,12 +308,31 @@ def main():
     run(rank * K * P, (rank + 1) * K * P, spp_total)
     if world > 1:
         ctx.synchronize()   # the render runs on the library's own streams; RCCL runs on torch's
-        reduce_to_rank0(rgb)
-        reduce_to_rank0(wsum)
+        reduce_to_rank0(film)
     fence()
     elapsed = time.perf_counter() - t0
 
     st = ctx.stats()
+    wmin = float(wsum.min()) if rank == 0 else 0.0
+
+    # BASELINE configs[2] as worded: one 1024-spp job, spp-sharded over the ranks, reduce included (strong scaling)
+    strong = None
+    if not args.no_strong and world <= STRONG_SPP:
+        sb, se = shard_range(STRONG_SPP, rank, world)
+        film.zero_()
+        ctx.reset_stats()
+        fence()
+        ts = time.perf_counter()
+        run(sb, se, STRONG_SPP)
+        if world > 1:
+            ctx.synchronize()
+            reduce_to_rank0(film)
+        fence()
+        strong_elapsed = time.perf_counter() - ts
+        sst = ctx.stats()
+        strong = (strong_elapsed, float(sst["rays_closest"] + sst["rays_any"]), float(sst["camera_samples"]),
+                  float(wsum.min()) if rank == 0 else 0.0, -(-(se - sb) // P))
+
     # k_extend alone on the device: one more step with the passes run one after the other (untimed). In the timed region
     # kernels of three passes share the CUs, which is faster overall but stretches every single launch.
     exclusive = None
@@ -176,11 +344,12 @@ def main():
             ctx.synchronize()
             sx = ctx.stats()
             if sx["extend_ms"] > 0:
-                exclusive = (float(sx["extend_rays"]), sx["extend_ms"], max(1, sx["extend_launches"]))
+                exclusive = sx
         finally:
             ctx.set_pipelines(3)
-    local = torch.tensor([elapsed, float(st["rays_closest"] + st["rays_any"]), float(st["camera_samples"]), float(st["extend_rays"]),
-                          st["extend_ms"], float(st["extend_launches"])], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    vals = [elapsed, float(st["rays_closest"] + st["rays_any"]), float(st["camera_samples"])]
+    vals += list(strong[:3]) if strong else [0.0, 0.0, 0.0]
+    local = torch.tensor(vals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     tmax = local.clone()
     tsum = local.clone()
     if world > 1:
@@ -191,13 +360,15 @@ def main():
 
     if rank == 0:
         # sanity: every pixel received exactly spp_total samples (plus rare border-rounded neighbours)
-        wmin = float(wsum.min())
         assert wmin >= spp_total, f"film incomplete: min weight {wmin} < {spp_total}"
         bpr = bytes_per_ray(ni, nl, nidx, ntri, closest=True)
-        ext_rays, ext_ms, ext_launches = float(st["extend_rays"]), st["extend_ms"], max(1, st["extend_launches"])
-        achieved = bpr * ext_rays / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
         fpr = flops_per_ray(ni, ntri, 1.0)
-        valu = fpr * ext_rays / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
+        ext_rays, ext_ms, ext_launches = float(st["extend_rays"]), st["extend_ms"], max(1, st["extend_launches"])
+        sh_ms, sh_launches = st["shade_ms"], max(1, st["shade_launches"])
+        ext_s = max(ext_ms, 1e-9) * 1e-3
+        valu = fpr * ext_rays / ext_s / 1e12
+        hbm = PMC["extend_hbm_bytes_per_ray"] * ext_rays / ext_s / 1e9
+        shade_gbs = SHADE_BYTES_PER_PATH * ext_rays / (max(sh_ms, 1e-9) * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (traversal+isect) and samples/sec, cornellBox 1080p, 1/2/4/8 GPUs",
             "value": rays / t / 1e6,
@@ -213,46 +384,82 @@ def main():
             "dtype": "f32",
             "data": "cornellBox scene of the reference (38 triangles, 133 KD nodes) from a committed fixture; camera rays generated on the device",
             "config": {
-                "workload": f"cornellBox PathTracing {WIDTH}x{HEIGHT}, depth {MAX_DEPTH}, {P} spp per step, counter RNG (BASELINE configs[2])",
+                "workload": f"cornellBox PathTracing {WIDTH}x{HEIGHT}, depth {MAX_DEPTH}, counter RNG (BASELINE configs[2]); a step is one "
+                            f"pass of {P} spp: this run renders {K * P} spp per GPU, {spp_total} spp in total (the configuration's own "
+                            f"1024-spp job is timed separately: strong_1024spp)",
                 "spp_per_gpu": K * P,
                 "spp_total": spp_total,
                 "paths_in_flight_per_gpu": WIDTH * HEIGHT * P,
-                "parallelism": f"spp-sharded x{world}, one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} sum-reduce of the {WIDTH}x{HEIGHT}x4 float film",
+                "parallelism": f"spp-sharded x{world}, one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} sum-reduce of the packed {WIDTH}x{HEIGHT}x4 float film",
             },
             "rays_per_sample": rays / samples,
             "roofline": {
-                "kernel": "k_extend (closest-hit KD traversal + triangle tests)",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": EXTEND_HBM_BYTES_PER_RAY_PMC * ext_rays / ext_launches,
-                "traffic_unit": "bytes per launch (HBM side, PMC)",
-                "bytes_per_ray": bpr,
+                "kernel": "k_extend (closest-hit KD traversal + triangle tests); the 8 KB of scene tables are staged in LDS",
+                "bound": "valu",
+                "achieved": valu,
+                "peak": FP32_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": valu / FP32_VALU_PEAK_TFLOPS,
+                "flops_per_ray": fpr,
+                "traffic": PMC["extend_hbm_bytes_per_ray"] * ext_rays / ext_launches,
+                "traffic_unit": "HBM-side bytes per launch (PMC bytes per ray x this run's rays per launch)",
                 "rays_per_launch": ext_rays / ext_launches,
                 "avg_launch_ms": ext_ms / ext_launches,
                 "launches": int(ext_launches),
                 "per_ray": {"interior": ni, "leaf": nl, "leaf_idx": nidx, "tri_tests": ntri},
-                "note": "algorithmic bytes (nodes, leaf indices and triangles are served from LDS for this 8 KB scene, so only the "
-                        "ray and hit records are HBM traffic); the kernel is bound by SIMD divergence (12.6 of 64 lanes active per "
-                        "VALU instruction, PMC), see valu",
-                "valu": {"achieved": valu, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu / FP32_VALU_PEAK_TFLOPS,
-                         "flops_per_ray": fpr},
+                "lanes_active_pmc": PMC["extend_lanes_active"],
+                "lds_bank_conflict_share_pmc": PMC["extend_lds_conflict_cycles"],
+                "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                        "bytes_per_ray_pmc": PMC["extend_hbm_bytes_per_ray"], "bytes_per_ray_unavoidable": 41.7},
+                "lds": {"bytes_per_ray_algorithmic": bpr - 44.0, "achieved_GBs": (bpr - 44.0) * ext_rays / ext_s / 1e9,
+                        "note": "node, leaf-index and triangle bytes: served from LDS, not HBM traffic"},
+                "pmc_source": PMC["source"],
+                "note": "the vector ALUs issue every cycle with about 12 of 64 lanes active (a wave ends with its slowest ray): what binds "
+                        "is VALU issue under SIMD divergence, so frac is the useful-flop fraction of the FP32 vector peak",
                 "extend_share_of_step": ext_ms * 1e-3 / t,
                 "launch_overlap": "durations in the timed region include time shared with the kernels of two other passes "
                                   "(three pipelines); 'exclusive' is the same kernel on the same queues with the passes "
                                   "run one after the other, outside the timed region",
             },
+            "roofline_shade": {
+                "kernel": "k_shade (one bounce of PathRenderer::Li per ray: NEE + MIS, BSDF sample, Russian roulette, queue appends)",
+                "bound": "hbm",
+                "achieved": shade_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": shade_gbs / HBM_PEAK_GBS,
+                "bytes_per_path": SHADE_BYTES_PER_PATH,
+                "traffic": PMC["shade_hbm_bytes_per_path"] * ext_rays / sh_launches,
+                "traffic_unit": "HBM-side bytes per launch (PMC)",
+                "avg_launch_ms": sh_ms / sh_launches,
+                "launches": int(sh_launches),
+                "lanes_active_pmc": PMC["shade_lanes_active"],
+                "shade_share_of_step": sh_ms * 1e-3 / t,
+            },
         }
         if exclusive is not None:
-            xr, xms, xl = exclusive
-            xa = bpr * xr / (xms * 1e-3) / 1e9
-            out["roofline"]["exclusive"] = {"achieved": xa, "unit": "GB/s", "frac": xa / HBM_PEAK_GBS, "avg_launch_ms": xms / xl,
-                                            "rays_per_launch": xr / xl}
+            xr, xms, xl = float(exclusive["extend_rays"]), exclusive["extend_ms"], max(1, exclusive["extend_launches"])
+            xv = fpr * xr / (xms * 1e-3) / 1e12
+            out["roofline"]["exclusive"] = {"achieved": xv, "unit": "TFLOP/s", "frac": xv / FP32_VALU_PEAK_TFLOPS, "avg_launch_ms": xms / xl,
+                                            "rays_per_launch": xr / xl,
+                                            "hbm_frac": PMC["extend_hbm_bytes_per_ray"] * xr / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if exclusive["shade_ms"] > 0:
+                xs = SHADE_BYTES_PER_PATH * xr / (exclusive["shade_ms"] * 1e-3) / 1e9
+                out["roofline_shade"]["exclusive"] = {"achieved": xs, "unit": "GB/s", "frac": xs / HBM_PEAK_GBS,
+                                                      "avg_launch_ms": exclusive["shade_ms"] / max(1, exclusive["shade_launches"])}
+        if strong:
+            ts_, srays, ssamples = float(tmax[3]), float(tsum[4]), float(tsum[5])
+            assert strong[3] >= STRONG_SPP, f"strong-scaling film incomplete: min weight {strong[3]}"
+            out["strong_1024spp"] = {"seconds": ts_, "samples_per_sec": ssamples / ts_, "Mrays_per_s": srays / ts_ / 1e6,
+                                     "per_gpu_passes": strong[4], "spp_per_gpu": STRONG_SPP // world, "n_gpus": world,
+                                     "note": "one 1024-spp job split by sample index over the ranks, film reduce included; max over ranks"}
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = soup_secondary(torch, dev, scene.config, with_cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cfg)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["gpu_over_reference_cpu"] = {"ratio": out["samples_per_sec"] / 1.617e6,
+                                             "reference": "1.617 M samples/s: the reference itself on 8 vCPU, cornellBox 800x800 x 512 spp (measured by the survey)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

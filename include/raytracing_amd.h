@@ -139,6 +139,9 @@ typedef struct rt_stats {
     double extend_ms;
     uint64_t extend_rays;      /* rays processed by those launches */
     double render_ms;          /* wall time of rt_render* calls (host clock, device-synchronised) */
+    /* HIP-event time of the shade kernel launches (one per bounce; they process the rays of extend_rays) */
+    uint64_t shade_launches;
+    double shade_ms;
     /* state of the context (not counters; rt_reset_stats leaves them alone) */
     uint64_t queue_bytes_per_pipeline;  /* device memory of one wavefront pipeline's queues and per-path state; 0 before the first Path render */
     uint64_t queue_paths;               /* paths in flight those queues are sized for */

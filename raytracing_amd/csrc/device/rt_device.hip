@@ -101,8 +101,8 @@ struct rt_context {
     unsigned long long *dStats = nullptr;
     int traceSchedule = RT_SCHEDULE_AUTO;
     int pipelines = RT_PIPES;   // RT_OPTION_PIPELINES
-    std::vector<EventPair> extendEvents;
-    size_t extendEventsUsed = 0;
+    std::vector<EventPair> extendEvents, shadeEvents;   // HIP events around every extend / shade launch of the path tracer
+    size_t extendEventsUsed = 0, shadeEventsUsed = 0;
     double renderMs = 0;
 
     // path tracer pipelines: consecutive passes rotate through kPipes sets of buffers, each on its own stream, so the
@@ -278,15 +278,24 @@ int ensure_path_buffers(rt_context *c, size_t nPaths, int maxDepth) {
     return RT_OK;
 }
 
-EventPair *next_event_pair(rt_context *c) {
-    if (c->extendEventsUsed >= 200000) return nullptr;
-    if (c->extendEventsUsed == c->extendEvents.size()) {
+EventPair *next_event_pair(std::vector<EventPair> &events, size_t &used) {
+    if (used >= 200000) return nullptr;
+    if (used == events.size()) {
         EventPair ep;
         if (hipEventCreate(&ep.a) != hipSuccess) return nullptr;
         if (hipEventCreate(&ep.b) != hipSuccess) { (void)hipEventDestroy(ep.a); return nullptr; }
-        c->extendEvents.push_back(ep);
+        events.push_back(ep);
     }
-    return &c->extendEvents[c->extendEventsUsed++];
+    return &events[used++];
+}
+
+double elapsed_ms(const std::vector<EventPair> &events, size_t used) {
+    double ms = 0;
+    for (size_t i = 0; i < used; ++i) {
+        float m = 0;
+        if (hipEventElapsedTime(&m, events[i].a, events[i].b) == hipSuccess) ms += m;
+    }
+    return ms;
 }
 
 // Grid of a streaming kernel: the workgroups the device keeps resident at once, so that every wave runs from the
@@ -450,7 +459,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
             const int cur = b & 1;
             // camera rays share their origin and have no origin records
             auto originsOf = [&](int bounce) { return bounce == 0 ? (const float4 *)nullptr : (const float4 *)pb.rayA[cur]; };
-            EventPair *ep = rs.timeExtend ? next_event_pair(c) : nullptr;
+            EventPair *ep = rs.timeExtend ? next_event_pair(c->extendEvents, c->extendEventsUsed) : nullptr;
             if (ep) HIPCHK(c, hipEventRecord(ep->a, st));
             if (streamTrace) {
                 auto kx = RT_PICK(k_extend_stream, c, stats);
@@ -464,7 +473,10 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
             if (ep) HIPCHK(c, hipEventRecord(ep->b, st));
             auto ksh = c->hasSpheres ? (c->allLambert ? k_shade<MATSET_LAMBERT, true> : k_shade<MATSET_ANY, true>)
                                      : (c->allLambert ? k_shade<MATSET_LAMBERT, false> : k_shade<MATSET_ANY, false>);
+            EventPair *es = rs.timeExtend ? next_event_pair(c->shadeEvents, c->shadeEventsUsed) : nullptr;
+            if (es) HIPCHK(c, hipEventRecord(es->a, st));
             hipLaunchKernelGGL(ksh, dim3(grid), dim3(RT_BLOCK), 0, st, c->sc, cam, ps, pb, b);
+            if (es) HIPCHK(c, hipEventRecord(es->b, st));
             if (b < p->max_depth) {
                 if (streamTrace) {
                     auto ks = RT_PICK(k_shadow_stream, c, stats);
@@ -811,7 +823,8 @@ static void destroy_one(rt_context *c) {
     if (c->dPixelState) (void)hipFree(c->dPixelState);
     if (c->dWhittedOffsets) (void)hipFree(c->dWhittedOffsets);
     if (c->dWhittedDraws) (void)hipFree(c->dWhittedDraws);
-    for (auto &ep : c->extendEvents) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (auto *events : {&c->extendEvents, &c->shadeEvents})
+        for (auto &ep : *events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1241,13 +1254,11 @@ static int get_stats_one(rt_context *c, rt_stats *out) {
     out->n_tri_tests = h[ST_TRI];
     out->counted_rays = h[ST_COUNTED_RAYS];
     out->extend_rays = h[ST_EXTEND_RAYS];
-    double ms = 0;
-    for (size_t i = 0; i < c->extendEventsUsed; ++i) {
-        float m = 0;
-        if (hipEventElapsedTime(&m, c->extendEvents[i].a, c->extendEvents[i].b) == hipSuccess) ms += m;
-    }
+    const double ms = elapsed_ms(c->extendEvents, c->extendEventsUsed);
     out->extend_launches = c->extendEventsUsed;
     out->extend_ms = ms;
+    out->shade_launches = c->shadeEventsUsed;
+    out->shade_ms = elapsed_ms(c->shadeEvents, c->shadeEventsUsed);
     out->render_ms = c->renderMs;
     out->queue_bytes_per_pipeline = c->pbBytesPerPipe;
     out->queue_paths = c->pbCapacity;
@@ -1261,7 +1272,7 @@ static int reset_stats_one(rt_context *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemset(c->dStats, 0, ST_COUNT * sizeof(unsigned long long)));
-    c->extendEventsUsed = 0;
+    c->extendEventsUsed = c->shadeEventsUsed = 0;
     c->renderMs = 0;
     return RT_OK;
 }
@@ -1376,7 +1387,7 @@ int rt_get_stats(rt_context *c, rt_stats *out) {
             out->rays_closest += s.rays_closest; out->rays_any += s.rays_any; out->camera_samples += s.camera_samples;
             out->n_interior += s.n_interior; out->n_leaf += s.n_leaf; out->n_leaf_idx += s.n_leaf_idx; out->n_tri_tests += s.n_tri_tests;
             out->counted_rays += s.counted_rays; out->extend_launches += s.extend_launches; out->extend_rays += s.extend_rays;
-            out->extend_ms += s.extend_ms;
+            out->extend_ms += s.extend_ms; out->shade_launches += s.shade_launches; out->shade_ms += s.shade_ms;
         } else if (rc) c->err = m->err;
     }
     if (!c->peers.empty()) (void)hipSetDevice(c->device);
