@@ -19,10 +19,10 @@
 #include "dtraverse.h"
 
 #ifndef RT_D_MAJ
-#define RT_D_MAJ 8           // keep descending while at least this many lanes are between leaves
+#define RT_D_MAJ 24          // keep descending while at least this many lanes are between leaves
 #endif
 #ifndef RT_T_MAJ
-#define RT_T_MAJ 24          // keep testing while at least this many lanes have leaf primitives left
+#define RT_T_MAJ 16          // keep testing while at least this many lanes have leaf primitives left
 #endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 16     // idle lanes needed before the wave prepares the next 64 rays
@@ -68,10 +68,13 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
         if (sp == 0) return false;
         --sp;
         tMin = tMax;   // the segment after the one just finished starts where that one ended
-        if (sp < SL) {
-            node = ldsStack[(sp * 2 + 0) * RT_BLOCK + tid];
-            tMax = __uint_as_float(ldsStack[(sp * 2 + 1) * RT_BLOCK + tid]);
-        } else {
+        // the LDS part is read unconditionally (clamped index) and the private part under its own branch: a single
+        // load through a pointer that may point to either becomes a flat load, which waits on both memory paths
+        const int e = sp < SL ? sp : SL - 1;
+        node = ldsStack[(e * 2 + 0) * RT_BLOCK + tid];
+        tMax = __uint_as_float(ldsStack[(e * 2 + 1) * RT_BLOCK + tid]);
+        asm volatile("" : "+v"(node), "+v"(tMax));   // keeps the two LDS reads as LDS reads (no merge with the branch below)
+        if (sp >= SL) {
             const int q = sp - SL;
             node = privNode[q];
             tMax = privTMax[q];
@@ -178,12 +181,12 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                             if (sp < SL) {
                                 ldsStack[(sp * 2 + 0) * RT_BLOCK + tid] = second;
                                 ldsStack[(sp * 2 + 1) * RT_BLOCK + tid] = __float_as_uint(tMax);
-                            } else {
+                            } else if (sp < RT_STACK_TOTAL) {
                                 const int q = sp - SL;
                                 privNode[q] = second;
                                 privTMax[q] = tMax;
                             }
-                            ++sp;
+                            sp = sp < RT_STACK_TOTAL ? sp + 1 : sp;   // see kd_trace: never taken for an accepted tree
                             node = first;
                             tMax = tPlane;
                         }

@@ -268,12 +268,14 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
                 if (sp < SL) {
                     ldsStack[(sp * 2 + 0) * RT_BLOCK + tid] = second;
                     ldsStack[(sp * 2 + 1) * RT_BLOCK + tid] = __float_as_uint(tMax);
-                } else {
+                } else if (sp < RT_STACK_TOTAL) {
                     const int q = sp - SL;
                     privNode[q] = second;
                     privTMax[q] = tMax;
                 }
-                ++sp;
+                // A tree that rt_upload_scene accepted never needs more than RT_STACK_TOTAL entries; should the tables be
+                // damaged in memory, the entry is dropped rather than written outside the stack.
+                sp = sp < RT_STACK_TOTAL ? sp + 1 : sp;
                 node = first;
                 tMax = tPlane;
             }
@@ -317,10 +319,12 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
         if (sp == 0) break;
         --sp;
         tMin = tMax;   // the segment after the one just finished starts where that one ended
-        if (sp < SL) {
-            node = ldsStack[(sp * 2 + 0) * RT_BLOCK + tid];
-            tMax = __uint_as_float(ldsStack[(sp * 2 + 1) * RT_BLOCK + tid]);
-        } else {
+        // LDS part read unconditionally (clamped index), private part under its own branch: see trace_stream's pop
+        const int e = sp < SL ? sp : SL - 1;
+        node = ldsStack[(e * 2 + 0) * RT_BLOCK + tid];
+        tMax = __uint_as_float(ldsStack[(e * 2 + 1) * RT_BLOCK + tid]);
+        asm volatile("" : "+v"(node), "+v"(tMax));   // keeps the two LDS reads as LDS reads (no merge with the branch below)
+        if (sp >= SL) {
             const int q = sp - SL;
             node = privNode[q];
             tMax = privTMax[q];

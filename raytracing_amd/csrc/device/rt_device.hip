@@ -207,7 +207,10 @@ int upload(rt_context *c, void **dst, const std::vector<T> &v, size_t padBytes =
     size_t bytes = v.size() * sizeof(T);
     size_t alloc = ((bytes + padBytes - 1) / padBytes) * padBytes + padBytes;
     HIPCHK(c, hipMalloc(dst, alloc));
-    HIPCHK(c, hipMemset(*dst, 0, alloc));
+    // The context's streams do not synchronise with the null stream, on which hipMemset runs asynchronously: every fill
+    // in this file goes to the context's own stream, followed by a wait where host copies or other streams come next.
+    HIPCHK(c, hipMemsetAsync(*dst, 0, alloc, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (bytes) HIPCHK(c, hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
     return RT_OK;
 }
@@ -238,8 +241,8 @@ int ensure_spill(rt_context *c) {
     c->spillPixels = 0;
     HIPCHK(c, hipMalloc((void **)&c->dSpillRgb, n * 3 * sizeof(float)));
     HIPCHK(c, hipMalloc((void **)&c->dSpillW, n * sizeof(float)));
-    HIPCHK(c, hipMemset(c->dSpillRgb, 0, n * 3 * sizeof(float)));
-    HIPCHK(c, hipMemset(c->dSpillW, 0, n * sizeof(float)));
+    HIPCHK(c, hipMemsetAsync(c->dSpillRgb, 0, n * 3 * sizeof(float), c->stream));   // the renderers' streams follow c->stream
+    HIPCHK(c, hipMemsetAsync(c->dSpillW, 0, n * sizeof(float), c->stream));
     c->spillPixels = n;
     c->spillDirty = false;
     return RT_OK;
@@ -801,7 +804,8 @@ int rt_create(int device_id, rt_context **out) {
     }
     if ((e = hipEventCreateWithFlags(&c->mainReady, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&c->dStats, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(c->dStats, 0, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemsetAsync(c->dStats, 0, ST_COUNT * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
     *out = c;
     return RT_OK;
 }
@@ -1271,7 +1275,8 @@ static int reset_stats_one(rt_context *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemset(c->dStats, 0, ST_COUNT * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->dStats, 0, ST_COUNT * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->extendEventsUsed = c->shadeEventsUsed = 0;
     c->renderMs = 0;
     return RT_OK;
