@@ -171,25 +171,27 @@ def soup_secondary(torch, dev, base_cfg, with_cpu):
             },
         },
     }
-    # path tracing on the same scene
+    # path tracing on the same scene: 16 spp is one pass; 128 spp is four passes of 32 spp that overlap on three pipelines
     ctx.set_camera(cfg)
     rgb = torch.zeros((cfg.height, cfg.width, 3), dtype=torch.float32, device=dev)
     w = torch.zeros((cfg.height, cfg.width), dtype=torch.float32, device=dev)
-    kw = dict(integrator=0, rng_mode=0, seed=1, spp=16, max_depth=MAX_DEPTH)
-    ctx.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)
-    ctx.synchronize()
-    rgb.zero_()
-    w.zero_()
-    ctx.reset_stats()
-    t0 = time.perf_counter()
-    ctx.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()
-    rays = st["rays_closest"] + st["rays_any"]
-    out["path_1080p_16spp"] = {"seconds": dt, "Mrays_per_s": rays / dt / 1e6, "samples_per_sec": st["camera_samples"] / dt,
-                               "rays_per_sample": rays / max(1, st["camera_samples"]),
-                               "extend_avg_launch_ms": st["extend_ms"] / max(1, st["extend_launches"])}
+    for spp in (16, 128):
+        kw = dict(integrator=0, rng_mode=0, seed=1, spp=spp, max_depth=MAX_DEPTH)
+        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)
+        ctx.synchronize()
+        rgb.zero_()
+        w.zero_()
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        rays = st["rays_closest"] + st["rays_any"]
+        assert float(w.min()) >= spp
+        out[f"path_1080p_{spp}spp"] = {"seconds": dt, "Mrays_per_s": rays / dt / 1e6, "samples_per_sec": st["camera_samples"] / dt,
+                                       "rays_per_sample": rays / max(1, st["camera_samples"]),
+                                       "extend_avg_launch_ms": st["extend_ms"] / max(1, st["extend_launches"])}
     ctx.close()
     if with_cpu:
         from concurrent.futures import ThreadPoolExecutor

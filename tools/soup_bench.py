@@ -100,24 +100,26 @@ def measure(scene, cfg, label, n, reps, depth):
         ctx.close()
         return
 
-    # path tracing (PathRenderer::Li) at 1920x1080, 16 spp
+    # path tracing (PathRenderer::Li) at 1920x1080, 16 spp in one pass (RT_HBM_SPP / RT_HBM_SPP_PASS: other job and pass sizes)
+    spp = int(os.environ.get("RT_HBM_SPP", "16"))
+    spp_pass = int(os.environ.get("RT_HBM_SPP_PASS", "0"))
     ctx.set_camera(cfg)
     rgb = torch.zeros((cfg.height, cfg.width, 3), dtype=torch.float32, device=dev)
     w = torch.zeros((cfg.height, cfg.width), dtype=torch.float32, device=dev)
     for schedule in schedules:
         ctx.set_trace_schedule(schedule)
-        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=16, max_depth=depth)
+        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=spp, max_depth=depth, spp_per_pass=spp_pass)
         ctx.synchronize()
         rgb.zero_()
         w.zero_()
         ctx.reset_stats()
         t0 = time.perf_counter()
-        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=16, max_depth=depth)
+        ctx.render_dev(rgb.data_ptr(), w.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=spp, max_depth=depth, spp_per_pass=spp_pass)
         ctx.synchronize()
         dt = time.perf_counter() - t0
         st = ctx.stats()
         rays = st["rays_closest"] + st["rays_any"]
-        print(json.dumps({"workload": f"{label}, PathTracing 1920x1080, 16 spp, depth {depth}", "schedule": schedule, "seconds": dt,
+        print(json.dumps({"workload": f"{label}, PathTracing 1920x1080, {spp} spp, depth {depth}", "schedule": schedule, "seconds": dt,
                           "Mrays_per_s": rays / dt / 1e6, "Msamples_per_s": st["camera_samples"] / dt / 1e6,
                           "rays_per_sample": rays / max(1, st["camera_samples"]), "extend_ms": st["extend_ms"],
                           "mean_rgb": [float(v) for v in (rgb.sum((0, 1)) / w.sum()).cpu()]}), flush=True)
