@@ -42,20 +42,20 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 # counters cannot be read inside a timed run, so the per-ray figures measured under the profiler are scaled by this run's
 # own ray counts and HIP-event times.
 PMC = {
-    "source": "profiles/r01_pmc_bench_steps4_v13.md",
+    "source": "profiles/r02_pmc_bench_steps4.md",
     # HBM-side bytes per ray of k_extend: 2 x 13.5 B read (gfx950's FETCH_SIZE counts 16-B-per-lane coalesced reads at
     # half their bytes; camera rays have no origin record) + 17.0 B written
     "extend_hbm_bytes_per_ray": 44.0,
-    "extend_lanes_active": 12.5,            # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, of 64
+    "extend_lanes_active": 12.6,            # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, of 64
     "extend_lds_conflict_cycles": 0.39,     # SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS
-    "shade_hbm_bytes_per_path": 103.0,      # k_shade: (FETCH_SIZE x 2 + WRITE_SIZE) per ray entering the kernel
-    "shade_lanes_active": 54.0,
+    "shade_hbm_bytes_per_path": 128.0,      # k_shade: (FETCH_SIZE x 2 + WRITE_SIZE) per ray entering the kernel
+    "shade_lanes_active": 54.3,
 }
 PMC_SOUP = {
-    "source": "profiles/r02_soup_base_pmc_incoherent.md",
-    "fetch_bytes_per_ray_raw": 3890.0,      # FETCH_SIZE per ray (64 B per request, no correction: 8-byte gathers)
-    "l2_hit_rate": 0.52,
-    "lanes_active": 18.3,
+    "source": "profiles/r02_soup_tuned_pmc_incoherent.md",
+    "fetch_bytes_per_ray_raw": 4067.0,      # FETCH_SIZE per ray (64 B per request, no correction: 8-byte gathers)
+    "l2_hit_rate": 0.50,
+    "lanes_active": 21.6,
 }
 
 
@@ -69,10 +69,10 @@ def flops_per_ray(ni, ntri, ncand):
     return 40 + 6 * ni + 44 * ntri + 35 * ncand
 
 
-# k_shade per ray entering it: the hit record (16 B) is read for every ray; a ray that hit (~85 % after bounce 0) reads
-# its direction record, throughput and generator state (48 B) and writes the next ray (32 B), throughput and generator
-# (32 B) and a shadow entry (48 B). Scene tables (80 B per primitive) stay in L2.
-SHADE_BYTES_PER_PATH = 16 + 0.85 * (48 + 32 + 32 + 48)
+# k_shade per ray entering it: the hit record (16 B) is read for every ray; a ray that hit (0.53 of the camera rays, 0.77 to
+# 0.86 of later rays: 0.70 over a pass) reads its direction record, throughput and generator state (48 B) and writes the
+# next ray (32 B), throughput and generator (32 B) and a shadow entry (48 B). Scene tables (80 B per primitive) stay in L2.
+SHADE_BYTES_PER_PATH = 16 + 0.70 * (48 + 32 + 32 + 48)
 
 
 def host_cores():

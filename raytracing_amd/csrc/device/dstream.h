@@ -18,11 +18,22 @@
 #pragma once
 #include "dtraverse.h"
 
+// Phase thresholds. A node step out of LDS costs little next to a primitive test, so a wave keeps descending with few lanes
+// (8) and switches to the tests when most lanes wait for one; a node step out of HBM costs a memory round trip whatever the
+// number of lanes, so there the wave leaves the descent as soon as fewer than 24 lanes want it. Measured, 8 / 24 against
+// 24 / 16: cornellBox bounce rays 14.9 / 13.8 G rays/s; 1 M-triangle soup, camera rays 1.30 / 1.65 G rays/s, path tracing
+// 429 / 474 M samples/s; 4 M-triangle mesh, incoherent rays 1.18 / 1.36 G rays/s.
+#ifndef RT_D_MAJ_LDS
+#define RT_D_MAJ_LDS 8       // tables in LDS: keep descending while at least this many lanes are between leaves
+#endif
+#ifndef RT_T_MAJ_LDS
+#define RT_T_MAJ_LDS 24      // tables in LDS: keep testing while at least this many lanes have leaf primitives left
+#endif
 #ifndef RT_D_MAJ
-#define RT_D_MAJ 24          // keep descending while at least this many lanes are between leaves
+#define RT_D_MAJ 24          // tables in HBM
 #endif
 #ifndef RT_T_MAJ
-#define RT_T_MAJ 16          // keep testing while at least this many lanes have leaf primitives left
+#define RT_T_MAJ 16          // tables in HBM
 #endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 16     // idle lanes needed before the wave prepares the next 64 rays
@@ -204,7 +215,7 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                     }
                 }
             }
-            if ((uint32_t)__popcll(__ballot(active && leafI >= leafN)) < RT_D_MAJ) break;
+            if ((uint32_t)__popcll(__ballot(active && leafI >= leafN)) < (PERM ? RT_D_MAJ_LDS : RT_D_MAJ)) break;   // PERM: tables in LDS
         }
         // test: one primitive per lane and round; more rounds while most of the wave is inside leaves
         for (;;) {
@@ -250,7 +261,7 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                     }
                 }
             }
-            if ((uint32_t)__popcll(__ballot(active && leafI < leafN)) < RT_T_MAJ) break;
+            if ((uint32_t)__popcll(__ballot(active && leafI < leafN)) < (PERM ? RT_T_MAJ_LDS : RT_T_MAJ)) break;
         }
     }
 }
