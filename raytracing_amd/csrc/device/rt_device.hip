@@ -797,7 +797,10 @@ int rt_create(int device_id, rt_context **out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->gridBlocks = c->numCUs * 8;
+#ifndef RT_GRID_BLOCKS_PER_CU
+#define RT_GRID_BLOCKS_PER_CU 8   // persistent grids: workgroups per CU (grid-stride loops over the device-resident queue counters)
+#endif
+    c->gridBlocks = c->numCUs * RT_GRID_BLOCKS_PER_CU;
     if ((e = scratch_address(device_id, &c->scratchPtr)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int k = 0; k < rt_context::kPipes; ++k) {
