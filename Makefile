@@ -3,6 +3,8 @@
 #   raytracing_amd/lib/libraytracing_amd.so  HIP kernels + C ABI for gfx950 (hipcc)
 #   oracle/liboracle.so                      CPU restatement used by tests / bench cpu_baseline (g++)
 # and tests/bin/abi_harness, a plain C caller of the device library's ABI (gcc) that the GPU tests run as a process.
+# `make emu` builds tests/bin/emu_trace_m0 / _m1: the tracing device headers compiled for the CPU with AddressSanitizer
+# (tests/test_emu_trace.py builds them itself when they are missing or stale).
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
@@ -37,7 +39,15 @@ tests/bin/abi_harness: tests/abi_harness.c include/raytracing_amd.h raytracing_a
 	gcc -std=c99 -O2 -Wall -Iinclude -o $@ tests/abi_harness.c -Lraytracing_amd/lib -lraytracing_amd \
 	    -Wl,-rpath,'$$ORIGIN/../../raytracing_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
-clean:
-	rm -f raytracing_amd/lib/*.so oracle/liboracle.so tests/bin/abi_harness
+EMU_SRC = tests/emu/emu_trace.cpp tests/emu/simt.h tests/emu/hip/hip_runtime.h
+EMU_FLAGS = -std=c++17 -O1 -g -fsanitize=address -static-libasan -fno-omit-frame-pointer -ffp-contract=off -Wall -Wno-unknown-pragmas \
+            -Wno-unused-function -Wno-unused-variable -DRT_STACK_LDS_LARGE=4 -Itests/emu
+emu: tests/bin/emu_trace_m0 tests/bin/emu_trace_m1
+tests/bin/emu_trace_m%: $(EMU_SRC) $(DEV_HDR)
+	@mkdir -p tests/bin
+	$(CXX) $(EMU_FLAGS) -DRT_STREAM_MERGED=$* -o $@ tests/emu/emu_trace.cpp
 
-.PHONY: all host device oracle harness clean
+clean:
+	rm -f raytracing_amd/lib/*.so oracle/liboracle.so tests/bin/abi_harness tests/bin/emu_trace_m0 tests/bin/emu_trace_m1
+
+.PHONY: all host device oracle harness emu clean

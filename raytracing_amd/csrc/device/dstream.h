@@ -43,6 +43,12 @@
 #endif
 
 
+// Tables in HBM: 1 = every round serves rays in all three states (node step, leaf index, primitive test) behind one wait;
+// 0 = the two phases below.
+#ifndef RT_STREAM_MERGED
+#define RT_STREAM_MERGED 0
+#endif
+
 #define RT_POOL_VEC_PER_RAY 4                                   // uint4 per prepared ray
 #define RT_POOL_BYTES (RT_BLOCK * RT_POOL_VEC_PER_RAY * 16)     // per workgroup: 64 prepared rays per wave
 
@@ -71,6 +77,8 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
     float rayTMax = 0.f, tMin = 0.f, tMax = 0.f;
     uint32_t node = 0, jobId = 0, leafBase = 0, triBase = 0;
     int sp = 0, leafI = 0, leafN = 0;
+    int prim = -1;   // merged rounds: the primitive to test next, -1 while its index is still to be read
+    constexpr bool MERGED = RT_STREAM_MERGED && !PERM;
     HitRec hit = {-1, 0.f, 0.f, 0.f, 0.f};
     bool active = false;
 
@@ -84,7 +92,7 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
         const int e = sp < SL ? sp : SL - 1;
         node = ldsStack[(e * 2 + 0) * RT_BLOCK + tid];
         tMax = __uint_as_float(ldsStack[(e * 2 + 1) * RT_BLOCK + tid]);
-        asm volatile("" : "+v"(node), "+v"(tMax));   // keeps the two LDS reads as LDS reads (no merge with the branch below)
+        RT_PIN_VGPRS(node, tMax);   // keeps the two LDS reads as LDS reads (no merge with the branch below)
         if (sp >= SL) {
             const int q = sp - SL;
             node = privNode[q];
@@ -169,6 +177,100 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
             }
         }
 
+        if constexpr (MERGED) {
+            // One round for all lanes: every ray issues the one load it needs next - a node, the first index of a leaf, or a
+            // primitive record together with the index of the leaf's next primitive - and the wave waits once for all of them.
+            // Lanes whose ray is in another state read entry 0 of the table (one cached line).
+            const bool wantNode = active && leafI >= leafN;
+            const bool wantIdx = active && leafI < leafN && prim < 0;
+            const bool wantTest = active && leafI < leafN && prim >= 0;
+            const bool moreInLeaf = wantTest && leafI + 1 < leafN;
+            const uint2 nd = tb.nodes[wantNode ? node : 0u];
+            const int idx = tb.leafIdx[wantIdx ? leafBase + (uint32_t)leafI : (moreInLeaf ? leafBase + (uint32_t)leafI + 1u : 0u)];
+            const uint32_t rec = wantTest ? 3u * (uint32_t)prim : 0u;
+            const float4 q0 = tb.triHot[rec + 0], q1 = tb.triHot[rec + 1], q2 = tb.triHot[rec + 2];
+            __builtin_amdgcn_sched_barrier(0);   // the loads above are issued before anything below waits for one of them
+            if (wantNode) {
+                if ((nd.y & 3u) != 3u) {
+                    if (STATS) ++cn.interior;
+                    const int axis = (int)(nd.y & 3u);
+                    const float split = __uint_as_float(nd.x);
+                    const float oa = comp3(r.o, axis), da = comp3(r.d, axis), ia = comp3(r.invDir, axis);
+                    const float tPlane = (split - oa) * ia;
+                    const bool belowFirst = (oa < split) || (oa == split && da <= 0);
+                    const uint32_t above = nd.y >> 2;
+                    const uint32_t first = belowFirst ? node + 1 : above;
+                    const uint32_t second = belowFirst ? above : node + 1;
+                    if (tPlane > tMax || tPlane <= 0) {
+                        node = first;
+                    } else if (tPlane < tMin) {
+                        node = second;
+                    } else {
+                        if (sp < SL) {
+                            ldsStack[(sp * 2 + 0) * RT_BLOCK + tid] = second;
+                            ldsStack[(sp * 2 + 1) * RT_BLOCK + tid] = __float_as_uint(tMax);
+                        } else if (sp < RT_STACK_TOTAL) {
+                            const int q = sp - SL;
+                            privNode[q] = second;
+                            privTMax[q] = tMax;
+                        }
+                        sp = sp < RT_STACK_TOTAL ? sp + 1 : sp;   // see kd_trace: never taken for an accepted tree
+                        node = first;
+                        tMax = tPlane;
+                    }
+                } else {
+                    if (STATS) ++cn.leaf;
+                    const int nP = (int)(nd.y >> 2);
+                    if (nP > 0) {
+                        leafN = nP;
+                        leafI = 0;
+                        leafBase = nd.x;
+                        prim = nP == 1 ? (int)nd.x : -1;   // a leaf of one primitive names it; a longer one names its index range
+                    } else if (!pop()) {   // empty leaf
+                        job.finish(jobId, hit);
+                        active = false;
+                    }
+                }
+            }
+            if (wantIdx) prim = idx;
+            if (wantTest) {
+                if (STATS) {
+                    ++cn.tri;
+                    if (leafN > 1) ++cn.leafIdx;
+                }
+                float t, b0, b1, b2;
+                ++leafI;
+                bool accepted;
+                if (SPH && q0.w == RT_PRIM_SPHERE) {
+                    f3 oo, dd;
+                    accepted = sphere_test(sc.spheres[__float_as_int(q0.x)], r.o, r.d, rayTMax, oo, dd, t);
+                    b0 = t;
+                    b1 = b2 = 0.f;
+                } else {
+                    accepted = tri_test<PERM>(r, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), rayTMax, t, b0, b1, b2);
+                }
+                if (accepted) {
+                    if (!CLOSEST) {
+                        hit.prim = prim;
+                        job.finish(jobId, hit);
+                        active = false;
+                    } else if (q0.w != RT_PRIM_DEGENERATE) {
+                        rayTMax = t;
+                        hit.prim = prim;
+                        hit.t = t;
+                        hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+                    }
+                }
+                prim = idx;   // the leaf's next primitive, if it has one
+                if (active && leafI == leafN) {
+                    leafI = leafN = 0;
+                    if (!pop()) {
+                        job.finish(jobId, hit);
+                        active = false;
+                    }
+                }
+            }
+        } else {
         // descend: one node per lane and round; more rounds while most of the wave is still between leaves
         for (;;) {
             if (active && leafI >= leafN) {
@@ -263,5 +365,39 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
             }
             if ((uint32_t)__popcll(__ballot(active && leafI < leafN)) < (PERM ? RT_T_MAJ_LDS : RT_T_MAJ)) break;
         }
+        }
     }
 }
+
+// Jobs of the batch entry points (rt_trace_closest / rt_trace_any): rays from three arrays, results to the caller's arrays.
+struct TraceClosestJob {
+    const float *o, *d, *tmax;
+    int *prim;
+    float *tOut, *bary;
+    RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
+        const size_t i = j;
+        ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        tm = tmax ? tmax[i] : RT_INF;
+        return true;
+    }
+    RT_DEV void finish(uint32_t j, const HitRec &h) const {
+        const size_t i = j;
+        if (prim) prim[i] = h.prim;
+        if (tOut) tOut[i] = h.t;
+        if (bary) { bary[3 * i] = h.b0; bary[3 * i + 1] = h.b1; bary[3 * i + 2] = h.b2; }
+    }
+};
+
+struct TraceAnyJob {
+    const float *o, *d, *tmax;
+    uint8_t *occluded;
+    RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
+        const size_t i = j;
+        ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        tm = tmax ? tmax[i] : RT_INF;
+        return true;
+    }
+    RT_DEV void finish(uint32_t j, const HitRec &h) const { occluded[j] = h.prim >= 0 ? 1 : 0; }
+};

@@ -21,6 +21,11 @@
 #ifndef RT_STACK_LDS_LARGE
 #define RT_STACK_LDS_LARGE 12
 #endif
+// Empty statement that the compiler must assume rewrites two vector registers: placed between two reads of a value, it
+// keeps the compiler from merging them into one read through a pointer.
+#ifndef RT_PIN_VGPRS
+#define RT_PIN_VGPRS(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#endif
 template <bool LDS_SCENE> struct StackCfg { static constexpr int LDS_N = LDS_SCENE ? RT_STACK_LDS_SMALL : RT_STACK_LDS_LARGE; };
 
 struct DevMaterial {
@@ -323,7 +328,7 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
         const int e = sp < SL ? sp : SL - 1;
         node = ldsStack[(e * 2 + 0) * RT_BLOCK + tid];
         tMax = __uint_as_float(ldsStack[(e * 2 + 1) * RT_BLOCK + tid]);
-        asm volatile("" : "+v"(node), "+v"(tMax));   // keeps the two LDS reads as LDS reads (no merge with the branch below)
+        RT_PIN_VGPRS(node, tMax);   // keeps the two LDS reads as LDS reads (no merge with the branch below)
         if (sp >= SL) {
             const int q = sp - SL;
             node = privNode[q];

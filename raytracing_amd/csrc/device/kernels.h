@@ -114,38 +114,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DevScene sc, uint64_t n,
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }
 
-struct TraceClosestJob {
-    const float *o, *d, *tmax;
-    int *prim;
-    float *tOut, *bary;
-    RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
-        const size_t i = j;
-        ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
-        rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        tm = tmax ? tmax[i] : RT_INF;
-        return true;
-    }
-    RT_DEV void finish(uint32_t j, const HitRec &h) const {
-        const size_t i = j;
-        if (prim) prim[i] = h.prim;
-        if (tOut) tOut[i] = h.t;
-        if (bary) { bary[3 * i] = h.b0; bary[3 * i + 1] = h.b1; bary[3 * i + 2] = h.b2; }
-    }
-};
-
-struct TraceAnyJob {
-    const float *o, *d, *tmax;
-    uint8_t *occluded;
-    RT_DEV bool fetch(uint32_t j, f3 &ro, f3 &rd, float &tm) const {
-        const size_t i = j;
-        ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
-        rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        tm = tmax ? tmax[i] : RT_INF;
-        return true;
-    }
-    RT_DEV void finish(uint32_t j, const HitRec &h) const { occluded[j] = h.prim >= 0 ? 1 : 0; }
-};
-
 // Streaming flavours. n < 2^32 (the host splits larger batches); the grid must be resident as a whole.
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_stream(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
