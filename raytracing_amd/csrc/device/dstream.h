@@ -48,6 +48,9 @@
 #ifndef RT_STREAM_MERGED
 #define RT_STREAM_MERGED 0
 #endif
+#ifndef RT_MERGED_T_MIN
+#define RT_MERGED_T_MIN 1    // merged rounds: lanes that must wait for a primitive test before the wave runs one
+#endif
 
 #define RT_POOL_VEC_PER_RAY 4                                   // uint4 per prepared ray
 #define RT_POOL_BYTES (RT_BLOCK * RT_POOL_VEC_PER_RAY * 16)     // per workgroup: 64 prepared rays per wave
@@ -183,7 +186,10 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
             // Lanes whose ray is in another state read entry 0 of the table (one cached line).
             const bool wantNode = active && leafI >= leafN;
             const bool wantIdx = active && leafI < leafN && prim < 0;
-            const bool wantTest = active && leafI < leafN && prim >= 0;
+            bool wantTest = active && leafI < leafN && prim >= 0;
+            // The test is the expensive section and runs at the same cost for one lane as for 64: with RT_MERGED_T_MIN > 1 the
+            // rays that wait for a test sit out rounds until that many wait, or until no ray wants a node step.
+            if (RT_MERGED_T_MIN > 1 && (uint32_t)__popcll(__ballot(wantTest)) < RT_MERGED_T_MIN && __ballot(wantNode || wantIdx) != 0ull) wantTest = false;
             const bool moreInLeaf = wantTest && leafI + 1 < leafN;
             const uint2 nd = tb.nodes[wantNode ? node : 0u];
             const int idx = tb.leafIdx[wantIdx ? leafBase + (uint32_t)leafI : (moreInLeaf ? leafBase + (uint32_t)leafI + 1u : 0u)];

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <map>
 #include <vector>
 
 namespace simt {
@@ -33,6 +34,7 @@ inline Launch launch = {};
 inline ucontext_t scheduler;
 inline std::function<void()> *body = nullptr;
 inline unsigned long long waveOps = 0;   // wave-wide operations evaluated so far (a run-away loop shows here)
+inline std::map<int, unsigned long long> opsAtLine;   // the same by source line (negative: wave barriers)
 
 [[noreturn]] inline void unsupported(const char *what) {
     std::fprintf(stderr, "simt: %s is not emulated\n", what);
@@ -101,6 +103,7 @@ inline bool run_wave(unsigned wave, std::function<void()> fn, unsigned long long
             lanes[l].waitingAt = 0;
         }
         ++waveOps;
+        ++opsAtLine[at];
         if (++ops > maxOps) {
             std::fprintf(stderr, "simt: wave still running after %llu wave-wide operations\n", ops);
             return false;
