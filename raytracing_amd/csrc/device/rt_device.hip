@@ -559,8 +559,6 @@ int render_whitted(rt_context *c, const rt_render_params *p, float *rgb, float *
         if (c->whittedScanCap < nSlotsPre) {
             if (c->dWhittedOffsets) (void)hipFree(c->dWhittedOffsets);
             if (c->dWhittedDraws) (void)hipFree(c->dWhittedDraws);
-    if (c->dGroupFilm) (void)hipFree(c->dGroupFilm);
-    if (c->groupDone) (void)hipEventDestroy(c->groupDone);
             c->dWhittedOffsets = c->dWhittedDraws = nullptr;
             c->whittedScanCap = 0;
             HIPCHK(c, hipMalloc((void **)&c->dWhittedOffsets, nSlotsPre * sizeof(unsigned long long) + 256 + (size_t)nTiles * sizeof(uint32_t)));
@@ -832,6 +830,8 @@ static void destroy_one(rt_context *c) {
     if (c->dPixelState) (void)hipFree(c->dPixelState);
     if (c->dWhittedOffsets) (void)hipFree(c->dWhittedOffsets);
     if (c->dWhittedDraws) (void)hipFree(c->dWhittedDraws);
+    if (c->dGroupFilm) (void)hipFree(c->dGroupFilm);
+    if (c->groupDone) (void)hipEventDestroy(c->groupDone);
     for (auto *events : {&c->extendEvents, &c->shadeEvents})
         for (auto &ep : *events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -51,6 +51,9 @@ def test_group_render_is_the_sum_of_its_shards(gpu_ctx, path_scene, members):
         a, aw = grp.render(**tk)
         b_, bw = gpu_ctx.render(**tk)
         assert np.array_equal(aw, bw) and np.array_equal(a, b_)
+        # the group's own buffers outlive that job (its offset search allocates on member 0): the first job again
+        rgb3, w3 = grp.render(**kw)
+        assert np.array_equal(w3, fw) and np.array_equal(rgb3, rgb)
         # fewer samples than members: member 0 renders them all
         a, aw = grp.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=2, spp=1, max_depth=3)
         b_, bw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=2, spp=1, max_depth=3)
