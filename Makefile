@@ -3,8 +3,9 @@
 #   raytracing_amd/lib/libraytracing_amd.so  HIP kernels + C ABI for gfx950 (hipcc)
 #   oracle/liboracle.so                      CPU restatement used by tests / bench cpu_baseline (g++)
 # and tests/bin/abi_harness, a plain C caller of the device library's ABI (gcc) that the GPU tests run as a process.
-# `make emu` builds tests/bin/emu_trace_m0 / _m1: the tracing device headers compiled for the CPU with AddressSanitizer
-# (tests/test_emu_trace.py builds them itself when they are missing or stale).
+# `make emu` builds the CPU checkers of tests/emu with AddressSanitizer: tests/bin/emu_trace_m0 / _m1 (the tracing device
+# headers) and tests/bin/emu_library (the whole device library, host code and kernels); tests/test_emu_*.py build them
+# themselves when they are missing or stale.
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
@@ -42,12 +43,15 @@ tests/bin/abi_harness: tests/abi_harness.c include/raytracing_amd.h raytracing_a
 EMU_SRC = tests/emu/emu_trace.cpp tests/emu/simt.h tests/emu/hip/hip_runtime.h
 EMU_FLAGS = -std=c++17 -O1 -g -fsanitize=address -static-libasan -fno-omit-frame-pointer -ffp-contract=off -Wall -Wno-unknown-pragmas \
             -Wno-unused-function -Wno-unused-variable -DRT_STACK_LDS_LARGE=4 -Itests/emu
-emu: tests/bin/emu_trace_m0 tests/bin/emu_trace_m1
+emu: tests/bin/emu_trace_m0 tests/bin/emu_trace_m1 tests/bin/emu_library
+tests/bin/emu_library: tests/emu/emu_library.cpp tests/emu/simt.h tests/emu/hip/hip_runtime.h tests/emu/rccl/rccl.h $(DEV_SRC) $(DEV_HDR)
+	@mkdir -p tests/bin
+	$(CXX) $(filter-out -DRT_STACK_LDS_LARGE=4,$(EMU_FLAGS)) -o $@ tests/emu/emu_library.cpp -ldl -lpthread
 tests/bin/emu_trace_m%: $(EMU_SRC) $(DEV_HDR)
 	@mkdir -p tests/bin
 	$(CXX) $(EMU_FLAGS) -DRT_STREAM_MERGED=$* -o $@ tests/emu/emu_trace.cpp
 
 clean:
-	rm -f raytracing_amd/lib/*.so oracle/liboracle.so tests/bin/abi_harness tests/bin/emu_trace_m0 tests/bin/emu_trace_m1
+	rm -f raytracing_amd/lib/*.so oracle/liboracle.so tests/bin/abi_harness tests/bin/emu_trace_m0 tests/bin/emu_trace_m1 tests/bin/emu_library
 
 .PHONY: all host device oracle harness emu clean

@@ -5,6 +5,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The workgroup's dynamic LDS (the size given at launch) as an array of uint4.
+#ifndef RT_DYNAMIC_LDS
+#define RT_DYNAMIC_LDS(name) extern __shared__ uint4 name[]
+#endif
+
 #define RT_DEV __device__ __forceinline__
 #define RT_HD __host__ __device__ __forceinline__
 

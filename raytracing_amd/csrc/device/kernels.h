@@ -73,7 +73,7 @@ template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                             const float *__restrict__ tmax, int *__restrict__ prim, float *__restrict__ tOut,
                                                             float *__restrict__ bary, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(DevScene sc, uint64_
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_any(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                         const float *__restrict__ tmax, uint8_t *__restrict__ occluded, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
@@ -119,7 +119,7 @@ template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_stream(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                                    const float *__restrict__ tmax, int *__restrict__ prim, float *__restrict__ tOut,
                                                                    float *__restrict__ bary, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
     TravCounters cn = {0, 0, 0, 0, 0};
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_stream(DevScene sc, 
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_any_stream(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
                                                                const float *__restrict__ tmax, uint8_t *__restrict__ occluded, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb, stream_lds_bytes<LDS_SCENE>());
     TravCounters cn = {0, 0, 0, 0, 0};
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, const float4 *
                                                      float4 *__restrict__ hit, const uint32_t *__restrict__ count, unsigned long long *stats,
                                                      float4 commonOrigin) {
     // rayA == nullptr: all rays start at commonOrigin (camera rays)
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     const uint32_t n = *count;
     if (blockIdx.x * RT_BLOCK >= n) return;   // whole block idle: skip the LDS staging
     SceneTables tb;
@@ -289,7 +289,7 @@ template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_stream(DevScene sc, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
                                                             float4 *__restrict__ hit, const uint32_t *__restrict__ count,
                                                             unsigned long long *stats, float4 commonOrigin) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     const uint32_t n = *count;
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
@@ -574,7 +574,7 @@ struct ShadowJob {
 
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow_stream(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     const uint32_t n = pb.counts[cnt_index(bounce, 1)];
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
@@ -638,7 +638,7 @@ RT_DEV void probe_entries(const DevScene &sc, const SceneTables &tb, uint32_t *s
 
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     const uint32_t n = pb.counts[cnt_index(bounce, 1)];
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, PathBuffers pb
 
 template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_probe(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     const uint32_t n = pb.counts[cnt_index(bounce, 2)];
     if (blockIdx.x * RT_BLOCK >= n) return;
     SceneTables tb;
@@ -1014,7 +1014,7 @@ template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_path_tile_stream(DevScene sc, CameraDev cam, int spp, int maxDepth, float rrThreshold, uint32_t nTiles,
                                                                uint32_t ntx, float *rgbSum, float *weightSum, float *spillRgb, float *spillW,
                                                                unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_path_tile_stream(DevScene sc, Came
 template <bool LDS_SCENE, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_whitted_prepass(DevScene sc, CameraDev cam, int spp, int maxDepth, uint32_t nTiles, uint32_t ntx,
                                                               uint2 *pixelState) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
@@ -1112,7 +1112,7 @@ template <bool LDS_SCENE, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_whitted_count(DevScene sc, CameraDev cam, int spp, int maxDepth, uint32_t nTiles, uint32_t ntx,
                                                             const unsigned long long *__restrict__ offsets, const uint32_t *__restrict__ tileLive,
                                                             unsigned long long *__restrict__ draws, uint2 *pixelState) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
@@ -1177,7 +1177,7 @@ template <bool LDS_SCENE, bool STATS, bool SPH>
 __global__ __launch_bounds__(RT_BLOCK) void k_whitted(DevScene sc, CameraDev cam, int sppBegin, int sppEnd, int sppTotal, int maxDepth, int rngMode,
                                                       uint64_t seed, const uint2 *pixelState, float *rgbSum, float *weightSum, float *spillRgb,
                                                       float *spillW, unsigned long long *stats) {
-    extern __shared__ uint4 smem[];
+    RT_DYNAMIC_LDS(smem);
     SceneTables tb;
     tables_setup<LDS_SCENE>(sc, smem, tb);
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem);
