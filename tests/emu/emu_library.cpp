@@ -1,23 +1,28 @@
 // The whole device library on the CPU: this translation unit includes raytracing_amd/csrc/device/rt_device.hip unchanged
-// (C ABI, host code, kernels) against the stand-ins tests/emu/hip/hip_runtime.h and tests/emu/rccl/rccl.h, and drives it
-// through include/raytracing_amd.h the way a host program does. Built with -fsanitize=address, every "device" buffer is a
-// heap block of its exact size, every release is a free, every launch runs its grid fibre by fibre before it returns: a
-// stale pointer, a buffer one element short, a table index out of range or a barrier that part of a workgroup misses
-// ends the run with a report. The test (tests/test_emu_library.py) compares what this program writes with the oracle.
+// (C ABI, host code, kernels) against the stand-ins tests/emu/hip/hip_runtime.h and tests/emu/rccl/rccl.h, and serves the
+// C ABI of include/raytracing_amd.h over its standard input and output, one call per request. Built with
+// -fsanitize=address, every "device" buffer is a heap block of its exact size, every release is a free, every launch runs
+// its grid fibre by fibre before it returns: a stale pointer, a buffer one element short, a table index out of range or
+// a barrier that part of a workgroup misses ends the process with a report on stderr. tests/emu_context.py is the client
+// (an object with the methods of raytracing_amd.device.Context); the tests compare what comes back with the oracle.
 // A checker for the library's source, not a second way to run it: the library itself has no CPU path.
 //
-//   emu_library <scene.bin> <rays.bin> <out.bin> <devices: 0 | 0,0> <any-hit tMax>
-//
-// scene.bin / rays.bin as written by tests/flatbin.py (the render job in scene.bin: spp, depth, seed). Sequence:
-//   1  rt_create_multi, rt_upload_scene, rt_set_camera
-//   2  for the lockstep and the streaming schedule: rt_trace_closest, rt_trace_any            -> out: 2 x {prim, t, bary, occluded}
-//   3  rt_render, Path, counter streams                                                        -> out: rgb, w
-//   4  rt_render, Whitted on the reference's tile streams, 2 spp (allocates its offset search) -> out: rgb, w
-//   5  rt_render as in 3 (buffers of 3 must have survived 4)                                   -> out: rgb, w
-//   6  rt_upload_scene again (tables released and rebuilt), rt_trace_closest                   -> out: prim, t, bary
-//   7  one device only: rt_render_noalloc_dev, Path as in 3                                    -> out: rgb, w
-//   8  rt_develop of 3's film                                                                  -> out: rgb8
-//   9  rt_get_stats, rt_destroy
+// Request:  uint32 op, uint64 payload bytes, payload.      Response: int32 rc, uint64 payload bytes, payload
+// (rc != 0: the payload is rt_last_error's text). Ops and payloads (all little-endian, arrays packed):
+//   1 create    int32 n, int32 device_ids[n]
+//   2 upload    uint32 n_nodes, n_leaf_idx, n_prims, n_materials, n_lights, n_spheres, flags (1 tri_n, 2 tri_uv, 4 shape_type);
+//               float bounds[6]; nodes, leaf_idx, tri_p, [tri_n], [tri_uv], material_id, light_id, materials, lights,
+//               [shape_type], spheres
+//   3 camera    float raster_to_camera[16], camera_to_world[16]; int32 width, height, sample_bounds[4]
+//   4 film      float radius_x, radius_y; int32 cropped_bounds[4]; float max_sample_luminance
+//   5 option    int32 option, value
+//   6 closest   uint64 n; uint32 has_tmax; float o[3n], d[3n], [tmax[n]]          -> int32 prim[n], float t[n], bary[3n]
+//   7 any       as 6                                                              -> uint8 occluded[n]
+//   8 render    rt_render_params; uint32 entry (0 rt_render, 1 rt_render_noalloc_dev); float rgb[3 W H], w[W H]  -> the same two
+//   9 develop   float film_scale; float rgb[3 W H], w[W H]                        -> uint8 rgb8[3 W H]
+//  10 stats                                                                       -> rt_stats
+//  11 reset_stats
+//  12 destroy
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -27,144 +32,179 @@
 
 namespace {
 
-template <typename T>
-std::vector<T> read_vec(FILE *f, size_t count) {
-    std::vector<T> v(count);
-    if (count && fread(v.data(), sizeof(T), count, f) != count) {
-        fprintf(stderr, "short read\n");
-        exit(2);
+struct Reader {
+    const std::vector<unsigned char> &buf;
+    size_t at = 0;
+    template <typename T> T one() {
+        T v;
+        take(&v, sizeof(T));
+        return v;
     }
-    return v;
+    template <typename T> std::vector<T> many(size_t count) {
+        std::vector<T> v(count);   // exact size: the library must not read past what the caller owns
+        take(v.data(), count * sizeof(T));
+        return v;
+    }
+    void take(void *dst, size_t bytes) {
+        if (at + bytes > buf.size()) {
+            fprintf(stderr, "emu_library: request shorter than its layout\n");
+            exit(2);
+        }
+        if (bytes) memcpy(dst, buf.data() + at, bytes);
+        at += bytes;
+    }
+};
+
+bool read_exact(void *dst, size_t bytes) { return bytes == 0 || fread(dst, 1, bytes, stdin) == bytes; }
+
+void respond(int rc, const void *payload, size_t bytes) {
+    const int32_t r = rc;
+    const uint64_t n = bytes;
+    fwrite(&r, 4, 1, stdout);
+    fwrite(&n, 8, 1, stdout);
+    if (bytes) fwrite(payload, 1, bytes, stdout);
+    fflush(stdout);
 }
 
-template <typename T>
-void write_vec(FILE *f, const std::vector<T> &v) {
-    if (!v.empty() && fwrite(v.data(), sizeof(T), v.size(), f) != v.size()) {
-        fprintf(stderr, "short write\n");
-        exit(2);
-    }
+template <typename T> void append(std::vector<unsigned char> &out, const std::vector<T> &v) {
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(v.data());
+    out.insert(out.end(), p, p + v.size() * sizeof(T));
 }
 
 }   // namespace
 
-#define CHECK(call)                                                                                             \
-    do {                                                                                                        \
-        const int rc_ = (call);                                                                                 \
-        if (rc_ != RT_OK) { fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, rt_last_error(ctx)); return 1; } \
-    } while (0)
-
-int main(int argc, char **argv) {
-    if (argc < 6) {
-        fprintf(stderr, "usage: %s scene.bin rays.bin out.bin devices anyhit_tmax\n", argv[0]);
-        return 2;
-    }
-    FILE *f = fopen(argv[1], "rb");
-    if (!f) { perror(argv[1]); return 2; }
-    uint32_t h[7];
-    int32_t ih[10];
-    uint64_t seed;
-    float bounds[6], r2c[16], c2w[16];
-    if (fread(h, 4, 7, f) != 7 || h[0] != 0x53465452u || fread(ih, 4, 10, f) != 10 || fread(&seed, 8, 1, f) != 1 || fread(bounds, 4, 6, f) != 6 ||
-        fread(r2c, 4, 16, f) != 16 || fread(c2w, 4, 16, f) != 16) {
-        fprintf(stderr, "bad scene header\n");
-        return 2;
-    }
-    rt_scene_desc sd = {};
-    sd.n_nodes = h[1]; sd.n_leaf_idx = h[2]; sd.n_prims = h[3]; sd.n_materials = h[4]; sd.n_lights = h[5];
-    memcpy(sd.bounds, bounds, sizeof bounds);
-    // exact-size host arrays: the library must not read past them either
-    const std::vector<uint32_t> nodes = read_vec<uint32_t>(f, 2 * (size_t)sd.n_nodes);
-    const std::vector<int32_t> leafIdx = read_vec<int32_t>(f, sd.n_leaf_idx);
-    const std::vector<float> triP = read_vec<float>(f, 9 * (size_t)sd.n_prims);
-    const std::vector<float> triN = h[6] ? read_vec<float>(f, 9 * (size_t)sd.n_prims) : std::vector<float>();
-    const std::vector<int32_t> matId = read_vec<int32_t>(f, sd.n_prims), lightId = read_vec<int32_t>(f, sd.n_prims);
-    const std::vector<rt_material> mats = read_vec<rt_material>(f, sd.n_materials);
-    const std::vector<rt_light> lights = read_vec<rt_light>(f, sd.n_lights);
-    fclose(f);
-    sd.nodes = nodes.data();
-    sd.leaf_idx = leafIdx.empty() ? nullptr : leafIdx.data();
-    sd.tri_p = triP.data();
-    sd.tri_n = triN.empty() ? nullptr : triN.data();
-    sd.material_id = matId.data();
-    sd.light_id = lightId.data();
-    sd.materials = mats.data();
-    sd.lights = lights.empty() ? nullptr : lights.data();
-
-    f = fopen(argv[2], "rb");
-    if (!f) { perror(argv[2]); return 2; }
-    uint64_t n = 0;
-    if (fread(&n, 8, 1, f) != 1) { fprintf(stderr, "bad ray file\n"); return 2; }
-    const std::vector<float> o = read_vec<float>(f, 3 * n), d = read_vec<float>(f, 3 * n);
-    fclose(f);
-
-    std::vector<int> devices;
-    for (const char *p = argv[4]; *p;) {
-        devices.push_back((int)strtol(p, (char **)&p, 10));
-        if (*p == ',') ++p;
-    }
-    const std::vector<float> tmaxAny(n, (float)atof(argv[5]));
-    FILE *out = fopen(argv[3], "wb");
-    if (!out) { perror(argv[3]); return 2; }
-
+int main() {
     rt_context *ctx = nullptr;
-    CHECK(rt_create_multi(devices.data(), (int)devices.size(), &ctx));
-    CHECK(rt_upload_scene(ctx, &sd));
-    const int width = ih[0], height = ih[1];
-    CHECK(rt_set_camera(ctx, r2c, c2w, width, height, &ih[2]));
-
-    std::vector<int32_t> prim(n);
-    std::vector<float> t(n), bary(3 * n);
-    std::vector<uint8_t> occ(n);
-    for (int schedule : {RT_SCHEDULE_LOCKSTEP, RT_SCHEDULE_STREAM}) {
-        CHECK(rt_set_option(ctx, RT_OPTION_TRACE_SCHEDULE, schedule));
-        CHECK(rt_trace_closest(ctx, n, o.data(), d.data(), nullptr, prim.data(), t.data(), bary.data()));
-        CHECK(rt_trace_any(ctx, n, o.data(), d.data(), tmaxAny.data(), occ.data()));
-        write_vec(out, prim); write_vec(out, t); write_vec(out, bary); write_vec(out, occ);
+    int width = 0, height = 0;
+    for (;;) {
+        uint32_t op;
+        uint64_t bytes;
+        if (!read_exact(&op, 4) || !read_exact(&bytes, 8)) break;   // the client closed the pipe
+        std::vector<unsigned char> payload(bytes);
+        if (!read_exact(payload.data(), bytes)) return 2;
+        Reader rd{payload};
+        std::vector<unsigned char> out;
+        int rc = RT_OK;
+        switch (op) {
+            case 1: {
+                const int32_t n = rd.one<int32_t>();
+                const std::vector<int32_t> ids = rd.many<int32_t>((size_t)n);
+                rc = rt_create_multi(ids.data(), n, &ctx);
+                break;
+            }
+            case 2: {
+                rt_scene_desc sd = {};
+                sd.n_nodes = rd.one<uint32_t>(); sd.n_leaf_idx = rd.one<uint32_t>(); sd.n_prims = rd.one<uint32_t>();
+                sd.n_materials = rd.one<uint32_t>(); sd.n_lights = rd.one<uint32_t>(); sd.n_spheres = rd.one<uint32_t>();
+                const uint32_t flags = rd.one<uint32_t>();
+                rd.take(sd.bounds, sizeof sd.bounds);
+                const auto nodes = rd.many<uint32_t>(2 * (size_t)sd.n_nodes);
+                const auto leafIdx = rd.many<int32_t>(sd.n_leaf_idx);
+                const auto triP = rd.many<float>(9 * (size_t)sd.n_prims);
+                const auto triN = rd.many<float>((flags & 1u) ? 9 * (size_t)sd.n_prims : 0);
+                const auto triUv = rd.many<float>((flags & 2u) ? 6 * (size_t)sd.n_prims : 0);
+                const auto matId = rd.many<int32_t>(sd.n_prims), lightId = rd.many<int32_t>(sd.n_prims);
+                const auto mats = rd.many<rt_material>(sd.n_materials);
+                const auto lights = rd.many<rt_light>(sd.n_lights);
+                const auto shapeType = rd.many<uint8_t>((flags & 4u) ? sd.n_prims : 0);
+                const auto spheres = rd.many<rt_sphere>(sd.n_spheres);
+                sd.nodes = nodes.data();
+                sd.leaf_idx = leafIdx.empty() ? nullptr : leafIdx.data();
+                sd.tri_p = triP.data();
+                sd.tri_n = triN.empty() ? nullptr : triN.data();
+                sd.tri_uv = triUv.empty() ? nullptr : triUv.data();
+                sd.material_id = matId.data();
+                sd.light_id = lightId.data();
+                sd.materials = mats.data();
+                sd.lights = lights.empty() ? nullptr : lights.data();
+                sd.shape_type = shapeType.empty() ? nullptr : shapeType.data();
+                sd.spheres = spheres.empty() ? nullptr : spheres.data();
+                rc = rt_upload_scene(ctx, &sd);   // the arrays above are released right after: the library keeps copies
+                break;
+            }
+            case 3: {
+                float r2c[16], c2w[16];
+                int32_t v[6];
+                rd.take(r2c, sizeof r2c); rd.take(c2w, sizeof c2w); rd.take(v, sizeof v);
+                rc = rt_set_camera(ctx, r2c, c2w, v[0], v[1], &v[2]);
+                if (rc == RT_OK) { width = v[0]; height = v[1]; }
+                break;
+            }
+            case 4: {
+                const float rx = rd.one<float>(), ry = rd.one<float>();
+                int32_t cb[4];
+                rd.take(cb, sizeof cb);
+                rc = rt_set_film(ctx, rx, ry, cb, rd.one<float>());
+                break;
+            }
+            case 5: {
+                const int32_t option = rd.one<int32_t>(), value = rd.one<int32_t>();
+                rc = rt_set_option(ctx, option, value);
+                break;
+            }
+            case 6:
+            case 7: {
+                const uint64_t n = rd.one<uint64_t>();
+                const uint32_t hasTMax = rd.one<uint32_t>();
+                const auto o = rd.many<float>(3 * n), d = rd.many<float>(3 * n);
+                const auto tmax = rd.many<float>(hasTMax ? n : 0);
+                if (op == 6) {
+                    std::vector<int32_t> prim(n);
+                    std::vector<float> t(n), bary(3 * n);
+                    rc = rt_trace_closest(ctx, n, o.data(), d.data(), hasTMax ? tmax.data() : nullptr, prim.data(), t.data(), bary.data());
+                    append(out, prim); append(out, t); append(out, bary);
+                } else {
+                    std::vector<uint8_t> occ(n);
+                    rc = rt_trace_any(ctx, n, o.data(), d.data(), hasTMax ? tmax.data() : nullptr, occ.data());
+                    append(out, occ);
+                }
+                break;
+            }
+            case 8: {
+                const rt_render_params p = rd.one<rt_render_params>();
+                const uint32_t entry = rd.one<uint32_t>();
+                const size_t npix = (size_t)width * height;
+                auto rgb = rd.many<float>(3 * npix), w = rd.many<float>(npix);
+                if (entry == 0) {
+                    rc = rt_render(ctx, &p, rgb.data(), w.data());
+                } else {
+                    // "device" pointers are heap pointers here
+                    rc = rt_render_noalloc_dev(ctx, &p, rgb.data(), w.data());
+                    if (rc == RT_OK) rc = rt_synchronize(ctx);
+                }
+                append(out, rgb); append(out, w);
+                break;
+            }
+            case 9: {
+                const float scale = rd.one<float>();
+                const size_t npix = (size_t)width * height;
+                const auto rgb = rd.many<float>(3 * npix), w = rd.many<float>(npix);
+                std::vector<uint8_t> rgb8(3 * npix);
+                rc = rt_develop(ctx, rgb.data(), w.data(), scale, rgb8.data());
+                append(out, rgb8);
+                break;
+            }
+            case 10: {
+                rt_stats st = {};
+                rc = rt_get_stats(ctx, &st);
+                const unsigned char *p = reinterpret_cast<const unsigned char *>(&st);
+                out.assign(p, p + sizeof st);
+                break;
+            }
+            case 11: rc = rt_reset_stats(ctx); break;
+            case 12:
+                rt_destroy(ctx);
+                ctx = nullptr;
+                break;
+            default: fprintf(stderr, "emu_library: unknown op %u\n", op); return 2;
+        }
+        if (rc != RT_OK) {
+            const std::string msg = rt_last_error(ctx);
+            respond(rc, msg.data(), msg.size());
+        } else {
+            respond(RT_OK, out.data(), out.size());
+        }
     }
-    CHECK(rt_set_option(ctx, RT_OPTION_TRACE_SCHEDULE, RT_SCHEDULE_AUTO));
-
-    const size_t npix = (size_t)width * height;
-    rt_render_params path = {};
-    path.integrator = RT_INTEGRATOR_PATH;
-    path.spp_total = ih[7];
-    path.spp_begin = 0;
-    path.spp_end = ih[7];
-    path.max_depth = ih[8];
-    path.rr_threshold = 1.0f;
-    path.rng_mode = RT_RNG_COUNTER;
-    path.seed = seed;
-    rt_render_params whitted = path;
-    whitted.integrator = RT_INTEGRATOR_WHITTED;
-    whitted.rng_mode = RT_RNG_REFERENCE_TILE_STREAM;
-    whitted.spp_total = whitted.spp_end = 2;
-    std::vector<float> film1;
-    for (const rt_render_params *job : {&path, &whitted, &path}) {
-        std::vector<float> rgb(3 * npix, 0.f), w(npix, 0.f);
-        CHECK(rt_render(ctx, job, rgb.data(), w.data()));
-        write_vec(out, rgb); write_vec(out, w);
-        if (film1.empty()) { film1 = rgb; film1.insert(film1.end(), w.begin(), w.end()); }
-    }
-
-    CHECK(rt_upload_scene(ctx, &sd));
-    CHECK(rt_trace_closest(ctx, n, o.data(), d.data(), nullptr, prim.data(), t.data(), bary.data()));
-    write_vec(out, prim); write_vec(out, t); write_vec(out, bary);
-
-    if (devices.size() == 1) {
-        // "device" pointers are heap pointers here; the entry point itself must not allocate (not checked by this program)
-        std::vector<float> rgb(3 * npix, 0.f), w(npix, 0.f);
-        CHECK(rt_render_noalloc_dev(ctx, &path, rgb.data(), w.data()));
-        CHECK(rt_synchronize(ctx));
-        write_vec(out, rgb); write_vec(out, w);
-    }
-    std::vector<uint8_t> rgb8(3 * npix);
-    CHECK(rt_develop(ctx, film1.data(), film1.data() + 3 * npix, 1.0f, rgb8.data()));
-    write_vec(out, rgb8);
-    rt_stats st;
-    CHECK(rt_get_stats(ctx, &st));
-    printf("%s: %d device(s), %llu rays per batch, %llu camera samples, %llu + %llu render rays, %llu wave-wide operations\n", rt_version(),
-           rt_device_count(ctx), (unsigned long long)n, (unsigned long long)st.camera_samples, (unsigned long long)st.rays_closest,
-           (unsigned long long)st.rays_any, simt::waveOps);
-    rt_destroy(ctx);
-    fclose(out);
+    if (ctx) rt_destroy(ctx);
     return 0;
 }

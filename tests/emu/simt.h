@@ -36,7 +36,7 @@ struct Launch {
 };
 
 constexpr int kBlockBarrier = 1 << 24;
-constexpr size_t kStackBytes = 512 * 1024;
+constexpr size_t kStackBytes = 96 * 1024;   // AddressSanitizer clears the shadow of a fibre's whole stack at every switch: keep it small
 
 inline Lane *current = nullptr;
 inline Launch launch = {};

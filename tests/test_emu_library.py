@@ -1,146 +1,271 @@
 """The whole device library - C ABI, host code and kernels of raytracing_amd/csrc/device/rt_device.hip, unchanged - compiled
-for the CPU (tests/emu/emu_library.cpp) and driven through the ABI under AddressSanitizer with leak detection: scene upload,
-both trace schedules, a Path render, a Whitted render on the reference's tile streams, the Path render again, a scene
-re-upload, the entry point that allocates nothing, film development, teardown; once on one device and once as a group
-of two members on that device. "Device" memory is the heap with exact sizes, streams run in order, every launch runs its grid
-as fibres that meet at ballots and barriers. Everything the program writes is compared with the oracle to the bars of the
-GPU tests: ids / t / barycentrics / occlusion bit-equal, Path film bit-equal (correctly rounded trig on both sides) up to
-reordered sums where samples of several passes meet, Whitted within 1e-4 per pixel.
+for the CPU (tests/emu/emu_library.cpp) and called through the ABI under AddressSanitizer with leak detection. "Device"
+memory is the heap at exact sizes, streams run in order, every launch runs its grid as fibres that meet at ballots and
+barriers. The tests below are small versions of the GPU parity tests and compare with the oracle to the same bars: ids /
+t / barycentrics / occlusion bit-equal, Path film bit-equal (correctly rounded trig on both sides) up to reordered sums
+where several passes or members meet, Whitted within 1e-4 per pixel. One server process serves the whole module, so what
+a call leaves behind (buffers, counters, options) meets the next call, as in a host program.
 The library has no CPU path; this is a checker of its source (memory safety of host and device code, barrier discipline,
 buffer lifetimes across calls), run where no GPU is needed."""
+import copy
 import os
-import shutil
-import subprocess
+from dataclasses import replace
 
 import numpy as np
 import pytest
 
-import flatbin
 import oracle_lib
 import raygen
+from emu_context import EmuContext, EmuError, build_server
 from oracle_lib import Oracle
 from raytracing_amd._ctypes_defs import RT_INTEGRATOR_PATH, RT_INTEGRATOR_WHITTED, RT_RNG_COUNTER, RT_RNG_REFERENCE_TILE_STREAM
+from raytracing_amd.scene import make_materials
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "tests", "bin")
-W, H, SPP, DEPTH, SEED = 48, 36, 4, 5, 3
-ANY_TMAX = 300.0
-
-
-def _build():
-    exe = os.path.join(BIN, "emu_library")
-    emu = os.path.join(ROOT, "tests", "emu")
-    dev = os.path.join(ROOT, "raytracing_amd", "csrc", "device")
-    sources = [os.path.join(emu, n) for n in ("emu_library.cpp", "simt.h", os.path.join("hip", "hip_runtime.h"), os.path.join("rccl", "rccl.h"))]
-    sources += [os.path.join(dev, n) for n in os.listdir(dev)] + [os.path.join(ROOT, "include", "raytracing_amd.h")]
-    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(s) for s in sources):
-        return exe
-    if shutil.which("g++") is None:
-        pytest.skip("no g++")
-    os.makedirs(BIN, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-static-libasan", "-fno-omit-frame-pointer", "-ffp-contract=off", "-Wall",
-           "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-variable", "-I" + emu, "-o", exe, sources[0], "-ldl", "-lpthread"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return exe
+W, H = 48, 36
 
 
 def _mean(rgb, w):
     return rgb / np.maximum(w, 1)[..., None]
 
 
+def _oracle(orc, **kw):
+    """The oracle with cos / sin / acos rounded once from double, which is what the kernels compute."""
+    oracle_lib.set_trig_mode(True)
+    try:
+        return orc.render(**kw)
+    finally:
+        oracle_lib.set_trig_mode(False)
+
+
+def _oracle_path(orc, **kw):
+    return _oracle(orc, integrator=RT_INTEGRATOR_PATH, **kw)
+
+
 @pytest.fixture(scope="module")
-def job(tmp_path_factory):
-    """A 32 x 16 x 2 mesh with Lambertian / mirror / glass stripes (tables in HBM on a GPU) and the cornellBox (tables in
-    LDS), each with rays and the oracle's answers."""
-    from raytracing_amd.scene import FlatScene
-    base = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornellBox_path.npz"))
-    out = {}
-    for name in ("cornell", "mesh"):
-        if name == "cornell":
-            scene, cfg = base, base.config.with_resolution(W, H)
-        else:
-            scene, cfg = raygen.grid_scene(32, 16, base.config, width=W, height=H)
-        orc = Oracle(scene, cfg)
-        oc, dc = raygen.camera_rays(orc, cfg, 700, seed=1)
-        oi, di = raygen.incoherent_rays(scene.bounds, 500, seed=3)
-        o, d = np.concatenate([oc, oi]), np.concatenate([dc, di])
-        if name == "mesh":
-            of, df = raygen.mesh_feature_rays(scene.tri_p[:-2], 600, seed=5)
-            o, d = np.concatenate([o, of]), np.concatenate([d, df])
-        prim, t, bary = orc.trace_closest(o, d)
-        occ = orc.trace_any(o, d, np.full(len(o), ANY_TMAX, np.float32))
-        oracle_lib.set_trig_mode(True)
-        try:
-            prgb, pw, _ = orc.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=SEED, max_depth=DEPTH, spp=SPP)
-        finally:
-            oracle_lib.set_trig_mode(False)
-        wrgb, ww, _ = orc.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=DEPTH, spp=2)
-        tmp = tmp_path_factory.mktemp("emu_" + name)
-        flatbin.write_scene(str(tmp / "scene.bin"), scene, cfg, RT_INTEGRATOR_PATH, SPP, DEPTH, RT_RNG_COUNTER, SEED)
-        flatbin.write_rays(str(tmp / "rays.bin"), o, d)
-        assert 0.3 < (prim >= 0).mean() and 0.05 < occ.mean() < 0.98 and _mean(prgb, pw).mean() > 0.005
-        out[name] = dict(tmp=tmp, n=len(o), prim=prim, t=t, bary=bary, occ=occ, path=(prgb, pw), whitted=(wrgb, ww))
-    return out
+def emu():
+    if build_server() is None:
+        pytest.skip("no g++")
+    ctx = EmuContext()
+    yield ctx
+    ctx.close()   # raises on a sanitizer report, leaks included
 
 
-@pytest.mark.parametrize("scene_name,devices", [("cornell", "0"), ("cornell", "0,0"), ("mesh", "0"), ("mesh", "0,0")])
-def test_library_on_the_cpu_under_asan_matches_the_oracle(job, scene_name, devices):
-    j = job[scene_name]
-    tmp, n = j["tmp"], j["n"]
-    out = tmp / f"out_{devices.replace(',', '_')}.bin"
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1")
-    r = subprocess.run([_build(), str(tmp / "scene.bin"), str(tmp / "rays.bin"), str(out), devices, str(ANY_TMAX)], capture_output=True, text=True,
-                       env=env, timeout=900)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
-    assert "ERROR: AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]
-    raw = np.fromfile(out, np.uint8)
-    at = 0
+def _check_traces(ctx, orc, o, d, tmax_any, label):
+    cp, ct, cb = orc.trace_closest(o, d)
+    ca = orc.trace_any(o, d, tmax_any)
+    try:
+        for schedule in ("lockstep", "stream"):
+            ctx.set_trace_schedule(schedule)
+            gp, gt, gb = ctx.trace_closest(o, d)
+            assert np.array_equal(gp, cp), f"{label}/{schedule}: {np.count_nonzero(gp != cp)} of {len(o)} primitive ids differ"
+            assert np.array_equal(gt.view(np.uint32), ct.view(np.uint32)), f"{label}/{schedule}"
+            assert np.array_equal(gb.view(np.uint32), cb.view(np.uint32)), f"{label}/{schedule}"
+            assert np.array_equal(ctx.trace_any(o, d, tmax_any), ca), f"{label}/{schedule}"
+    finally:
+        ctx.set_trace_schedule("auto")
+    return cp, ca
 
-    def take(count, dtype):
-        nonlocal at
-        size = count * np.dtype(dtype).itemsize
-        a = raw[at:at + size].view(dtype)
-        at += size
-        return a
 
-    npix = W * H
-
-    def take_trace(with_occ=True):
-        return (take(n, np.int32), take(n, np.float32), take(3 * n, np.float32).reshape(n, 3), take(n, np.uint8) if with_occ else None)
-
-    def take_film():
-        return take(3 * npix, np.float32).reshape(H, W, 3), take(npix, np.float32).reshape(H, W)
-
-    def check_trace(got, label):
-        gp, gt, gb, go = got
-        assert np.array_equal(gp, j["prim"]), f"{label}: {np.count_nonzero(gp != j['prim'])} of {n} primitive ids differ"
-        assert np.array_equal(gt.view(np.uint32), j["t"].view(np.uint32)), label
-        assert np.array_equal(gb.view(np.uint32), j["bary"].view(np.uint32)), label
-        if go is not None:
-            assert np.array_equal(go, j["occ"]), label
-
-    def check_path(got, label):
-        rgb, w = got
-        crgb, cw = j["path"]
-        assert np.array_equal(w, cw), label
+def _check_path(got, want, label, exact=True):
+    (rgb, w), (crgb, cw) = got, want[:2]
+    assert np.array_equal(w, cw), label
+    assert np.abs(rgb - crgb).max() <= 4e-6 * np.abs(crgb).max(), label
+    if exact:
         neq = (rgb != crgb).any(axis=2)
-        assert np.abs(rgb - crgb).max() <= 4e-6 * np.abs(crgb).max(), label
-        if devices == "0":   # a group adds its members' films, i.e. the same samples in another association
-            assert neq.mean() <= 2e-3, f"{label}: {np.count_nonzero(neq)} pixels differ"
+        assert neq.mean() <= 2e-3, f"{label}: {np.count_nonzero(neq)} pixels differ"
 
-    check_trace(take_trace(), "lockstep")
-    check_trace(take_trace(), "stream")
-    first = take_film()
-    check_path(first, "path")
-    wrgb, ww = take_film()
-    assert np.array_equal(ww, j["whitted"][1])
-    assert np.abs(_mean(wrgb, ww) - _mean(*j["whitted"])).max() <= 1e-4
-    again = take_film()
+
+@pytest.mark.parametrize("scene_name", ["cornell", "mesh"])
+def test_session_one_device(emu, path_scene, scene_name):
+    """Upload, both schedules, Path, Whitted on tile streams (allocates its offset search), Path again, second upload,
+    the entry point that allocates nothing, development - on the cornellBox (tables in LDS on a GPU) and on a 32 x 16 x 2
+    mesh with Lambertian / mirror / glass stripes (tables in HBM), rays at shared vertices and edges included."""
+    if scene_name == "cornell":
+        scene, cfg = path_scene, path_scene.config.with_resolution(W, H)
+    else:
+        scene, cfg = raygen.grid_scene(32, 16, path_scene.config, width=W, height=H)
+    orc = Oracle(scene, cfg)
+    oc, dc = raygen.camera_rays(orc, cfg, 700, seed=1)
+    oi, di = raygen.incoherent_rays(scene.bounds, 500, seed=3)
+    o, d = np.concatenate([oc, oi]), np.concatenate([dc, di])
+    if scene_name == "mesh":
+        of, df = raygen.mesh_feature_rays(scene.tri_p[:-2], 600, seed=5)
+        o, d = np.concatenate([o, of]), np.concatenate([d, df])
+    tmax_any = np.random.RandomState(2).uniform(0, 400, len(o)).astype(np.float32)
+    emu.upload_scene(scene)
+    emu.set_camera(cfg)
+    assert emu.stats()["scene_in_lds"] == (1 if scene_name == "cornell" else 0)
+    prim, occ = _check_traces(emu, orc, o, d, tmax_any, scene_name)
+    assert 0.3 < (prim >= 0).mean() and 0.05 < occ.mean() < 0.98
+    kw = dict(rng_mode=RT_RNG_COUNTER, seed=3, max_depth=5, spp=4)
+    want = _oracle_path(orc, **kw)
+    assert _mean(*want[:2]).mean() > 0.005
+    first = emu.render(integrator=RT_INTEGRATOR_PATH, **kw)
+    _check_path(first, want, "path")
+    wk = dict(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=5, spp=2)
+    wrgb, ww = emu.render(**wk)
+    crgb, cw, _ = orc.render(**wk)
+    assert np.array_equal(ww, cw) and np.abs(_mean(wrgb, ww) - _mean(crgb, cw)).max() <= 1e-4
+    again = emu.render(integrator=RT_INTEGRATOR_PATH, **kw)
     assert np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1]), "the same job after a Whitted job"
-    check_trace(take_trace(with_occ=False), "after the second upload")
-    if devices == "0":
-        check_path(take_film(), "rt_render_noalloc_dev")
-    rgb8 = take(3 * npix, np.uint8)
-    assert at == raw.size
-    assert rgb8.max() > 40, "the developed film is not black"
+    emu.upload_scene(scene)
+    emu.set_camera(cfg)
+    gp, gt, gb = emu.trace_closest(o, d)
+    cp, ct, cb = orc.trace_closest(o, d)
+    assert np.array_equal(gp, cp) and np.array_equal(gt.view(np.uint32), ct.view(np.uint32)) and np.array_equal(gb.view(np.uint32), cb.view(np.uint32))
+    _check_path(emu.render_noalloc(integrator=RT_INTEGRATOR_PATH, **kw), want, "rt_render_noalloc_dev")
+    # accumulation into the caller's film, in shards and in passes of 3 samples over the pipelines
+    rgb, w = first[0].copy(), first[1].copy()
+    for b, e in ((0, 1), (1, 4)):
+        rgb, w = emu.render(integrator=RT_INTEGRATOR_PATH, spp_begin=b, spp_end=e, spp_per_pass=3, rgb_sum=rgb, weight_sum=w, **kw)
+    assert np.array_equal(w, 2 * want[1]) and np.abs(rgb - 2 * want[0]).max() <= 1e-5 * np.abs(want[0]).max()
+    rgb8 = emu.develop(*first)
+    assert rgb8.shape == (H, W, 3) and rgb8.max() > 40
+
+
+def test_group_of_two_members():
+    """rt_create_multi with the device listed twice: members' films summed on the device; a tile-stream Whitted job (member
+    0 alone, allocates) between two group jobs; teardown of both members."""
+    from raytracing_amd.scene import FlatScene
+    if build_server() is None:
+        pytest.skip("no g++")
+    base = FlatScene.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornellBox_path.npz"))
+    cfg = base.config.with_resolution(W, H)
+    orc = Oracle(base, cfg)
+    kw = dict(rng_mode=RT_RNG_COUNTER, seed=3, max_depth=5, spp=5)
+    want = _oracle_path(orc, **kw)
+    with EmuContext(device_ids=(0, 0)) as grp:
+        grp.upload_scene(base)
+        grp.set_camera(cfg)
+        grp.reset_stats()
+        first = grp.render(integrator=RT_INTEGRATOR_PATH, **kw)
+        assert grp.stats()["camera_samples"] == W * H * 5, "every sample once across the members"
+        _check_path(first, want, "group", exact=False)   # the members' films are added: the same samples in another association
+        wk = dict(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, max_depth=4, spp=2)
+        wrgb, ww = grp.render(**wk)
+        crgb, cw, _ = orc.render(**wk)
+        assert np.array_equal(ww, cw) and np.abs(_mean(wrgb, ww) - _mean(crgb, cw)).max() <= 1e-4
+        again = grp.render(integrator=RT_INTEGRATOR_PATH, **kw)
+        assert np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
+        o, d = raygen.camera_rays(orc, cfg, 300, seed=4)
+        gp, _, _ = grp.trace_closest(o, d)
+        assert np.array_equal(gp, orc.trace_closest(o, d)[0])
+
+
+def test_spheres_and_specular_materials(emu, path_scene, sphere_scene):
+    """The sphere flavours of every kernel (cornell.json: mirror sphere, emissive sphere) and mirror / glass boxes, both
+    integrators, counter streams and the reference's tile streams."""
+    mixed = copy.copy(path_scene)
+    mats = mixed.materials.copy()
+    mats[6] = make_materials([(2, (0.9, 0.9, 0.9), 1.5)])[0]    # short box: glass
+    mats[7] = make_materials([(1, (0.8, 0.8, 0.8), 1.0)])[0]    # tall box: mirror
+    mixed.materials = mats
+    for label, scene in (("spheres", sphere_scene), ("mixed", mixed)):
+        cfg = scene.config.with_resolution(40, 40, spp=3)
+        orc = Oracle(scene, cfg)
+        emu.upload_scene(scene)
+        emu.set_camera(cfg)
+        oc, dc = raygen.camera_rays(orc, cfg, 600, seed=11)
+        os_, ds = raygen.surface_rays(orc, oc, dc, seed=12)
+        o, d = np.concatenate([oc, os_]), np.concatenate([dc, ds])
+        _check_traces(emu, orc, o, d, np.full(len(o), 250.0, np.float32), label)
+        for rng_mode in (RT_RNG_COUNTER, RT_RNG_REFERENCE_TILE_STREAM):
+            kw = dict(rng_mode=rng_mode, seed=5, max_depth=6)
+            emu.reset_stats()
+            got = emu.render(integrator=RT_INTEGRATOR_PATH, **kw)
+            st = emu.stats()
+            want = _oracle_path(orc, **kw)
+            _check_path(got, want, f"{label} path {rng_mode}")
+            if rng_mode == RT_RNG_REFERENCE_TILE_STREAM:
+                assert st["rays_closest"] == want[2]["rays_closest"] and st["rays_any"] == want[2]["rays_any"]
+            wrgb, ww = emu.render(integrator=RT_INTEGRATOR_WHITTED, **kw)
+            crgb, cw, _ = _oracle(orc, integrator=RT_INTEGRATOR_WHITTED, **kw)
+            assert np.array_equal(ww, cw) and np.abs(_mean(wrgb, ww) - _mean(crgb, cw)).max() <= 1e-4, f"{label} whitted {rng_mode}"
+
+
+def test_film_window_wide_filter_and_clamp(emu, path_scene):
+    """rt_set_film: cropped pixel bounds, a Box filter wider than a pixel (neighbours' samples arrive through float atomics
+    and the spill buffers) and MaxLum, both integrators; then the full window, whose sample bounds start at negative
+    film coordinates."""
+    base = path_scene.config.with_resolution(40, 28, spp=3)
+    cfg = replace(base, cropped_bounds=(4, 3, 35, 25)).with_filter((1.0, 1.5), max_sample_luminance=1.5)
+    emu.upload_scene(path_scene)
+    for c in (cfg, base.with_filter((1.0, 1.5))):
+        orc = Oracle(path_scene, c)
+        emu.set_camera(c)
+        for integrator in (RT_INTEGRATOR_WHITTED, RT_INTEGRATOR_PATH):
+            kw = dict(rng_mode=RT_RNG_COUNTER, seed=9, max_depth=4)
+            grgb, gw = emu.render(integrator=integrator, spp_per_pass=2, **kw)
+            oracle_lib.set_trig_mode(True)
+            try:
+                crgb, cw, _ = orc.render(integrator=integrator, **kw)
+            finally:
+                oracle_lib.set_trig_mode(False)
+            assert np.array_equal(gw, cw)
+            np.testing.assert_allclose(grgb, crgb, rtol=2e-5, atol=1e-6)
+    assert not gw[:0].any() and gw.min() > 0
+    with pytest.raises(EmuError, match="rt error"):
+        emu._call(4, __import__("struct").pack("<2f4if", 0.5, 0.5, 0, 0, 41, 28, float("inf")))   # cropped bounds outside the film
+
+
+def test_traversal_counters_and_ray_counts(emu, path_scene):
+    """The instrumented kernel flavours (counters in every traversal) against the oracle's counts."""
+    cfg = path_scene.config.with_resolution(W, H, spp=2)
+    orc = Oracle(path_scene, cfg)
+    emu.upload_scene(path_scene)
+    emu.set_camera(cfg)
+    o, d = raygen.camera_rays(orc, cfg, 900, seed=13)
+    emu.reset_stats()
+    emu.trace_closest(o, d)
+    st = emu.stats()
+    _, _, _, cn = orc.trace_closest(o, d, counters=True)
+    assert st["counted_rays"] == len(o)
+    assert st["n_interior"] == cn["n_interior"] and st["n_leaf"] == cn["n_leaf"]
+    assert st["n_tri_tests"] == cn["n_tri_tests"] and st["n_leaf_idx"] == cn["n_leaf_idx"]
+    emu.reset_stats()
+    got = emu.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=6, collect_stats=True)
+    st = emu.stats()
+    want = _oracle_path(orc, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=6, collect_stats=True)
+    _check_path(got, want, "path with counters")
+    assert st["camera_samples"] == want[2]["camera_samples"] == W * H * 2
+    assert st["rays_closest"] == want[2]["rays_closest"] and st["rays_any"] == want[2]["rays_any"]
+    assert st["n_tri_tests"] == want[2]["n_tri_tests"] and st["n_interior"] == want[2]["n_interior"]
+
+
+def test_todo_stack_at_its_limit_and_rejected_input(emu, path_scene):
+    """A chain of 64 interior nodes whose planes a ray meets far to near fills the todo stack to its 64th entry
+    (Accelerators/KDTree.cpp:396-398: todo[64]); one node more is refused at upload. Bad arguments come back as errors."""
+    def chain(n_interior):
+        # interior node i: plane x = 500 - i, below child i + 1, above child = the empty leaf at the end
+        nodes = np.zeros((n_interior + 2, 2), np.uint32)
+        for i in range(n_interior):
+            nodes[i, 0] = np.float32(500 - i).view(np.uint32)
+            nodes[i, 1] = (n_interior + 1) << 2
+        nodes[n_interior] = (0, 3)        # empty leaves
+        nodes[n_interior + 1] = (0, 3)
+        s = copy.copy(path_scene)
+        s.nodes = nodes
+        s.leaf_idx = np.zeros(0, np.int32)
+        return s
+
+    deep = chain(64)
+    emu.upload_scene(deep)
+    orc = Oracle(deep, deep.config)
+    n = 200
+    rs = np.random.RandomState(3)
+    o = np.stack([rs.uniform(1, 50, n), rs.uniform(10, 500, n), rs.uniform(10, 500, n)], axis=1).astype(np.float32)
+    d = np.stack([np.ones(n), rs.uniform(-0.05, 0.05, n), rs.uniform(-0.05, 0.05, n)], axis=1)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    _, _, _, cn = orc.trace_closest(o, d, counters=True)
+    assert cn["max_stack"] == 64
+    _check_traces(emu, orc, o, d, np.full(n, 1000.0, np.float32), "64-entry chain")
+    with pytest.raises(EmuError, match="deeper"):
+        emu.upload_scene(chain(65))
+    emu.upload_scene(path_scene)
+    with pytest.raises(EmuError, match="rt error"):
+        emu.set_option(1, 7)
+    with pytest.raises(EmuError, match="rt error"):
+        emu.render(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_COUNTER, spp=2, max_depth=33)
+    empty = np.zeros((0, 3), np.float32)
+    gp, gt, gb = emu.trace_closest(empty, empty)
+    assert len(gp) == 0 and len(emu.trace_any(empty, empty)) == 0
