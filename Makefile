@@ -41,7 +41,7 @@ tests/bin/abi_harness: tests/abi_harness.c include/raytracing_amd.h raytracing_a
 	    -Wl,-rpath,'$$ORIGIN/../../raytracing_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
 EMU_SRC = tests/emu/emu_trace.cpp tests/emu/simt.h tests/emu/hip/hip_runtime.h
-EMU_FLAGS = -std=c++17 -O1 -g -fsanitize=address -static-libasan -fno-omit-frame-pointer -ffp-contract=off -Wall -Wno-unknown-pragmas \
+EMU_FLAGS = -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -static-libasan -static-libubsan -fno-omit-frame-pointer -ffp-contract=off -Wall -Wno-unknown-pragmas \
             -Wno-unused-function -Wno-unused-variable -DRT_STACK_LDS_LARGE=4 -Itests/emu
 emu: tests/bin/emu_trace_m0 tests/bin/emu_trace_m1 tests/bin/emu_library
 tests/bin/emu_library: tests/emu/emu_library.cpp tests/emu/simt.h tests/emu/hip/hip_runtime.h tests/emu/rccl/rccl.h $(DEV_SRC) $(DEV_HDR)

@@ -1,7 +1,7 @@
 // The whole device library on the CPU: this translation unit includes raytracing_amd/csrc/device/rt_device.hip unchanged
 // (C ABI, host code, kernels) against the stand-ins tests/emu/hip/hip_runtime.h and tests/emu/rccl/rccl.h, and serves the
 // C ABI of include/raytracing_amd.h over its standard input and output, one call per request. Built with
-// -fsanitize=address, every "device" buffer is a heap block of its exact size, every release is a free, every launch runs
+// -fsanitize=address,undefined, every "device" buffer is a heap block of its exact size, every release is a free, every launch runs
 // its grid fibre by fibre before it returns: a stale pointer, a buffer one element short, a table index out of range or
 // a barrier that part of a workgroup misses ends the process with a report on stderr. tests/emu_context.py is the client
 // (an object with the methods of raytracing_amd.device.Context); the tests compare what comes back with the oracle.
@@ -71,11 +71,126 @@ template <typename T> void append(std::vector<unsigned char> &out, const std::ve
     out.insert(out.end(), p, p + v.size() * sizeof(T));
 }
 
+// One function per request (a single function with every request's buffers takes the sanitizer minutes to compile).
+struct Session {
+    rt_context *ctx = nullptr;
+    int width = 0, height = 0;
+};
+
+int op_create(Session &s, Reader &rd) {
+    const int32_t n = rd.one<int32_t>();
+    const std::vector<int32_t> ids = rd.many<int32_t>((size_t)n);
+    return rt_create_multi(ids.data(), n, &s.ctx);
+}
+
+int op_upload(Session &s, Reader &rd) {
+    rt_scene_desc sd = {};
+    sd.n_nodes = rd.one<uint32_t>(); sd.n_leaf_idx = rd.one<uint32_t>(); sd.n_prims = rd.one<uint32_t>();
+    sd.n_materials = rd.one<uint32_t>(); sd.n_lights = rd.one<uint32_t>(); sd.n_spheres = rd.one<uint32_t>();
+    const uint32_t flags = rd.one<uint32_t>();
+    rd.take(sd.bounds, sizeof sd.bounds);
+    const auto nodes = rd.many<uint32_t>(2 * (size_t)sd.n_nodes);
+    const auto leafIdx = rd.many<int32_t>(sd.n_leaf_idx);
+    const auto triP = rd.many<float>(9 * (size_t)sd.n_prims);
+    const auto triN = rd.many<float>((flags & 1u) ? 9 * (size_t)sd.n_prims : 0);
+    const auto triUv = rd.many<float>((flags & 2u) ? 6 * (size_t)sd.n_prims : 0);
+    const auto matId = rd.many<int32_t>(sd.n_prims), lightId = rd.many<int32_t>(sd.n_prims);
+    const auto mats = rd.many<rt_material>(sd.n_materials);
+    const auto lights = rd.many<rt_light>(sd.n_lights);
+    const auto shapeType = rd.many<uint8_t>((flags & 4u) ? sd.n_prims : 0);
+    const auto spheres = rd.many<rt_sphere>(sd.n_spheres);
+    sd.nodes = nodes.data();
+    sd.leaf_idx = leafIdx.empty() ? nullptr : leafIdx.data();
+    sd.tri_p = triP.data();
+    sd.tri_n = triN.empty() ? nullptr : triN.data();
+    sd.tri_uv = triUv.empty() ? nullptr : triUv.data();
+    sd.material_id = matId.data();
+    sd.light_id = lightId.data();
+    sd.materials = mats.data();
+    sd.lights = lights.empty() ? nullptr : lights.data();
+    sd.shape_type = shapeType.empty() ? nullptr : shapeType.data();
+    sd.spheres = spheres.empty() ? nullptr : spheres.data();
+    return rt_upload_scene(s.ctx, &sd);   // the arrays above are released right after: the library keeps copies
+}
+
+int op_camera(Session &s, Reader &rd) {
+    float r2c[16], c2w[16];
+    int32_t v[6];
+    rd.take(r2c, sizeof r2c); rd.take(c2w, sizeof c2w); rd.take(v, sizeof v);
+    const int rc = rt_set_camera(s.ctx, r2c, c2w, v[0], v[1], &v[2]);
+    if (rc == RT_OK) { s.width = v[0]; s.height = v[1]; }
+    return rc;
+}
+
+int op_film(Session &s, Reader &rd) {
+    const float rx = rd.one<float>(), ry = rd.one<float>();
+    int32_t cb[4];
+    rd.take(cb, sizeof cb);
+    return rt_set_film(s.ctx, rx, ry, cb, rd.one<float>());
+}
+
+int op_option(Session &s, Reader &rd) {
+    const int32_t option = rd.one<int32_t>(), value = rd.one<int32_t>();
+    return rt_set_option(s.ctx, option, value);
+}
+
+int op_trace(Session &s, Reader &rd, bool closest, std::vector<unsigned char> &out) {
+    const uint64_t n = rd.one<uint64_t>();
+    const uint32_t hasTMax = rd.one<uint32_t>();
+    const auto o = rd.many<float>(3 * n), d = rd.many<float>(3 * n);
+    const auto tmax = rd.many<float>(hasTMax ? n : 0);
+    int rc;
+    if (closest) {
+        std::vector<int32_t> prim(n);
+        std::vector<float> t(n), bary(3 * n);
+        rc = rt_trace_closest(s.ctx, n, o.data(), d.data(), hasTMax ? tmax.data() : nullptr, prim.data(), t.data(), bary.data());
+        append(out, prim); append(out, t); append(out, bary);
+    } else {
+        std::vector<uint8_t> occ(n);
+        rc = rt_trace_any(s.ctx, n, o.data(), d.data(), hasTMax ? tmax.data() : nullptr, occ.data());
+        append(out, occ);
+    }
+    return rc;
+}
+
+int op_render(Session &s, Reader &rd, std::vector<unsigned char> &out) {
+    const rt_render_params p = rd.one<rt_render_params>();
+    const uint32_t entry = rd.one<uint32_t>();
+    const size_t npix = (size_t)s.width * s.height;
+    auto rgb = rd.many<float>(3 * npix), w = rd.many<float>(npix);
+    int rc;
+    if (entry == 0) {
+        rc = rt_render(s.ctx, &p, rgb.data(), w.data());
+    } else {
+        rc = rt_render_noalloc_dev(s.ctx, &p, rgb.data(), w.data());   // "device" pointers are heap pointers here
+        if (rc == RT_OK) rc = rt_synchronize(s.ctx);
+    }
+    append(out, rgb); append(out, w);
+    return rc;
+}
+
+int op_develop(Session &s, Reader &rd, std::vector<unsigned char> &out) {
+    const float scale = rd.one<float>();
+    const size_t npix = (size_t)s.width * s.height;
+    const auto rgb = rd.many<float>(3 * npix), w = rd.many<float>(npix);
+    std::vector<uint8_t> rgb8(3 * npix);
+    const int rc = rt_develop(s.ctx, rgb.data(), w.data(), scale, rgb8.data());
+    append(out, rgb8);
+    return rc;
+}
+
+int op_stats(Session &s, std::vector<unsigned char> &out) {
+    rt_stats st = {};
+    const int rc = rt_get_stats(s.ctx, &st);
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&st);
+    out.assign(p, p + sizeof st);
+    return rc;
+}
+
 }   // namespace
 
 int main() {
-    rt_context *ctx = nullptr;
-    int width = 0, height = 0;
+    Session s;
     for (;;) {
         uint32_t op;
         uint64_t bytes;
@@ -86,125 +201,30 @@ int main() {
         std::vector<unsigned char> out;
         int rc = RT_OK;
         switch (op) {
-            case 1: {
-                const int32_t n = rd.one<int32_t>();
-                const std::vector<int32_t> ids = rd.many<int32_t>((size_t)n);
-                rc = rt_create_multi(ids.data(), n, &ctx);
-                break;
-            }
-            case 2: {
-                rt_scene_desc sd = {};
-                sd.n_nodes = rd.one<uint32_t>(); sd.n_leaf_idx = rd.one<uint32_t>(); sd.n_prims = rd.one<uint32_t>();
-                sd.n_materials = rd.one<uint32_t>(); sd.n_lights = rd.one<uint32_t>(); sd.n_spheres = rd.one<uint32_t>();
-                const uint32_t flags = rd.one<uint32_t>();
-                rd.take(sd.bounds, sizeof sd.bounds);
-                const auto nodes = rd.many<uint32_t>(2 * (size_t)sd.n_nodes);
-                const auto leafIdx = rd.many<int32_t>(sd.n_leaf_idx);
-                const auto triP = rd.many<float>(9 * (size_t)sd.n_prims);
-                const auto triN = rd.many<float>((flags & 1u) ? 9 * (size_t)sd.n_prims : 0);
-                const auto triUv = rd.many<float>((flags & 2u) ? 6 * (size_t)sd.n_prims : 0);
-                const auto matId = rd.many<int32_t>(sd.n_prims), lightId = rd.many<int32_t>(sd.n_prims);
-                const auto mats = rd.many<rt_material>(sd.n_materials);
-                const auto lights = rd.many<rt_light>(sd.n_lights);
-                const auto shapeType = rd.many<uint8_t>((flags & 4u) ? sd.n_prims : 0);
-                const auto spheres = rd.many<rt_sphere>(sd.n_spheres);
-                sd.nodes = nodes.data();
-                sd.leaf_idx = leafIdx.empty() ? nullptr : leafIdx.data();
-                sd.tri_p = triP.data();
-                sd.tri_n = triN.empty() ? nullptr : triN.data();
-                sd.tri_uv = triUv.empty() ? nullptr : triUv.data();
-                sd.material_id = matId.data();
-                sd.light_id = lightId.data();
-                sd.materials = mats.data();
-                sd.lights = lights.empty() ? nullptr : lights.data();
-                sd.shape_type = shapeType.empty() ? nullptr : shapeType.data();
-                sd.spheres = spheres.empty() ? nullptr : spheres.data();
-                rc = rt_upload_scene(ctx, &sd);   // the arrays above are released right after: the library keeps copies
-                break;
-            }
-            case 3: {
-                float r2c[16], c2w[16];
-                int32_t v[6];
-                rd.take(r2c, sizeof r2c); rd.take(c2w, sizeof c2w); rd.take(v, sizeof v);
-                rc = rt_set_camera(ctx, r2c, c2w, v[0], v[1], &v[2]);
-                if (rc == RT_OK) { width = v[0]; height = v[1]; }
-                break;
-            }
-            case 4: {
-                const float rx = rd.one<float>(), ry = rd.one<float>();
-                int32_t cb[4];
-                rd.take(cb, sizeof cb);
-                rc = rt_set_film(ctx, rx, ry, cb, rd.one<float>());
-                break;
-            }
-            case 5: {
-                const int32_t option = rd.one<int32_t>(), value = rd.one<int32_t>();
-                rc = rt_set_option(ctx, option, value);
-                break;
-            }
-            case 6:
-            case 7: {
-                const uint64_t n = rd.one<uint64_t>();
-                const uint32_t hasTMax = rd.one<uint32_t>();
-                const auto o = rd.many<float>(3 * n), d = rd.many<float>(3 * n);
-                const auto tmax = rd.many<float>(hasTMax ? n : 0);
-                if (op == 6) {
-                    std::vector<int32_t> prim(n);
-                    std::vector<float> t(n), bary(3 * n);
-                    rc = rt_trace_closest(ctx, n, o.data(), d.data(), hasTMax ? tmax.data() : nullptr, prim.data(), t.data(), bary.data());
-                    append(out, prim); append(out, t); append(out, bary);
-                } else {
-                    std::vector<uint8_t> occ(n);
-                    rc = rt_trace_any(ctx, n, o.data(), d.data(), hasTMax ? tmax.data() : nullptr, occ.data());
-                    append(out, occ);
-                }
-                break;
-            }
-            case 8: {
-                const rt_render_params p = rd.one<rt_render_params>();
-                const uint32_t entry = rd.one<uint32_t>();
-                const size_t npix = (size_t)width * height;
-                auto rgb = rd.many<float>(3 * npix), w = rd.many<float>(npix);
-                if (entry == 0) {
-                    rc = rt_render(ctx, &p, rgb.data(), w.data());
-                } else {
-                    // "device" pointers are heap pointers here
-                    rc = rt_render_noalloc_dev(ctx, &p, rgb.data(), w.data());
-                    if (rc == RT_OK) rc = rt_synchronize(ctx);
-                }
-                append(out, rgb); append(out, w);
-                break;
-            }
-            case 9: {
-                const float scale = rd.one<float>();
-                const size_t npix = (size_t)width * height;
-                const auto rgb = rd.many<float>(3 * npix), w = rd.many<float>(npix);
-                std::vector<uint8_t> rgb8(3 * npix);
-                rc = rt_develop(ctx, rgb.data(), w.data(), scale, rgb8.data());
-                append(out, rgb8);
-                break;
-            }
-            case 10: {
-                rt_stats st = {};
-                rc = rt_get_stats(ctx, &st);
-                const unsigned char *p = reinterpret_cast<const unsigned char *>(&st);
-                out.assign(p, p + sizeof st);
-                break;
-            }
-            case 11: rc = rt_reset_stats(ctx); break;
+            case 1: rc = op_create(s, rd); break;
+            case 2: rc = op_upload(s, rd); break;
+            case 3: rc = op_camera(s, rd); break;
+            case 4: rc = op_film(s, rd); break;
+            case 5: rc = op_option(s, rd); break;
+            case 6: rc = op_trace(s, rd, true, out); break;
+            case 7: rc = op_trace(s, rd, false, out); break;
+            case 8: rc = op_render(s, rd, out); break;
+            case 9: rc = op_develop(s, rd, out); break;
+            case 10: rc = op_stats(s, out); break;
+            case 11: rc = rt_reset_stats(s.ctx); break;
             case 12:
-                rt_destroy(ctx);
-                ctx = nullptr;
+                rt_destroy(s.ctx);
+                s.ctx = nullptr;
                 break;
             default: fprintf(stderr, "emu_library: unknown op %u\n", op); return 2;
         }
         if (rc != RT_OK) {
-            const std::string msg = rt_last_error(ctx);
+            const std::string msg = rt_last_error(s.ctx);
             respond(rc, msg.data(), msg.size());
         } else {
             respond(RT_OK, out.data(), out.size());
         }
     }
-    if (ctx) rt_destroy(ctx);
+    if (s.ctx) rt_destroy(s.ctx);
     return 0;
 }

@@ -17,16 +17,18 @@
 #define __device__
 #define __host__
 #define __global__
-#define __forceinline__ inline __attribute__((always_inline))
+#define __forceinline__ inline   /* forced inlining of the kernels' helpers costs the sanitizer build minutes */
 #define __launch_bounds__(...)
 #define __shared__ static          /* a workgroup-wide array inside a kernel: one copy for the fibres of the running workgroup */
 #define __align__(n) alignas(n)
 #define HIP_SYMBOL(x) x
 #define RT_DYNAMIC_LDS(name) uint4 *name = reinterpret_cast<uint4 *>(simt::dynamicLds)
 
-struct float4 { float x, y, z, w; };
-struct uint4 { uint32_t x, y, z, w; };
-struct uint2 { uint32_t x, y; };
+// aligned as HIP's vector types are, so that UndefinedBehaviorSanitizer reports a vector access at an address the GPU's wide
+// loads and stores could not take
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct alignas(8) uint2 { uint32_t x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }

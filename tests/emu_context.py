@@ -28,7 +28,7 @@ def build_server():
     if shutil.which("g++") is None:
         return None
     os.makedirs(BIN, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-static-libasan", "-fno-omit-frame-pointer", "-ffp-contract=off", "-Wall",
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-static-libasan", "-static-libubsan", "-fno-omit-frame-pointer", "-ffp-contract=off", "-Wall",
            "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-variable", "-I" + emu, "-o", exe, sources[0], "-ldl", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -34,7 +34,7 @@ def _build(merged, t_min=1):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     os.makedirs(BIN, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-static-libasan", "-fno-omit-frame-pointer", "-ffp-contract=off",
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-static-libasan", "-static-libubsan", "-fno-omit-frame-pointer", "-ffp-contract=off",
            "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-variable", f"-DRT_STREAM_MERGED={merged}", f"-DRT_MERGED_T_MIN={t_min}",
            f"-DRT_STACK_LDS_LARGE={STACK_LDS}",
            "-I" + os.path.join(ROOT, "tests", "emu"), "-o", exe, sources[0]]
