@@ -8,7 +8,7 @@
 # themselves when they are missing or stale.
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
-CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -pthread
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function
 
 HOST_SRC = $(wildcard raytracing_amd/csrc/host/*.cpp)

@@ -62,6 +62,10 @@ int rt_host_build(uint32_t n_prims, const float *tri_p, const float *tri_n, cons
 
 void rt_host_free(rt_host_scene *s);
 
+/* Threads the KD-tree build of the next rt_host_load_json / rt_host_build may use (the reference builds on one,
+ * Accelerators/KDTree.cpp:86-129): 0 = as many as the machine has (default), 1 = one. The tree is the same either way. */
+void rt_host_set_build_threads(int threads);
+
 /* Pointers stay valid until rt_host_free. */
 const rt_scene_desc *rt_host_scene_desc(const rt_host_scene *s);
 int rt_host_get_config(const rt_host_scene *s, rt_host_config *out);

@@ -39,7 +39,8 @@ struct KdTreeFlat {
     int maxDepthParam = 0;
 };
 
-// maxDepth <= 0 selects round(8 + 1.3 log2 N) like the reference (Accelerators/KDTree.cpp:95-98).
-void kd_build(const std::vector<Box3> &primBounds, KdTreeFlat &out, int maxDepth = -1);
+// maxDepth <= 0 selects round(8 + 1.3 log2 N) like the reference (Accelerators/KDTree.cpp:95-98). threads <= 0: as many as
+// the machine has (at most 32); the arrays are the same for every thread count.
+void kd_build(const std::vector<Box3> &primBounds, KdTreeFlat &out, int maxDepth = -1, int threads = 0);
 
 }  // namespace rth

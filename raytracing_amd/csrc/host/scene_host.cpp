@@ -21,6 +21,7 @@ using namespace rth;
 namespace {
 
 thread_local std::string g_err;
+int g_buildThreads = 0;   // rt_host_set_build_threads
 
 // ---- property values ---------------------------------------------------------------------------
 // The reference turns every JSON leaf into a string and parses it again on use
@@ -186,7 +187,7 @@ struct rt_host_scene {
             for (int k = 1; k < 8; ++k) b = box_union(b, xf_apply(m, corner[k], 1.0f));
             pb[sp.prim_id] = b;
         }
-        kd_build(pb, tree);
+        kd_build(pb, tree, -1, g_buildThreads);
         desc.n_nodes = (uint32_t)(tree.nodes.size() / 2);
         desc.nodes = tree.nodes.data();
         desc.n_leaf_idx = (uint32_t)tree.leafIdx.size();
@@ -430,6 +431,8 @@ int rt_host_build(uint32_t n_prims, const float *tri_p, const float *tri_n, cons
 }
 
 void rt_host_free(rt_host_scene *s) { delete s; }
+
+void rt_host_set_build_threads(int threads) { g_buildThreads = threads < 0 ? 0 : threads; }
 
 const rt_scene_desc *rt_host_scene_desc(const rt_host_scene *s) { return s ? &s->desc : nullptr; }
 

@@ -30,6 +30,8 @@ def host_lib():
         lib.rt_host_build.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
         lib.rt_host_free.argtypes = [C.c_void_p]
+        lib.rt_host_set_build_threads.argtypes = [C.c_int]
+        lib.rt_host_set_build_threads.restype = None
         lib.rt_host_scene_desc.argtypes = [C.c_void_p]
         lib.rt_host_scene_desc.restype = C.POINTER(RtSceneDesc)
         lib.rt_host_get_config.argtypes = [C.c_void_p, C.POINTER(RtHostConfig)]
