@@ -269,3 +269,33 @@ def test_todo_stack_at_its_limit_and_rejected_input(emu, path_scene):
     empty = np.zeros((0, 3), np.float32)
     gp, gt, gb = emu.trace_closest(empty, empty)
     assert len(gp) == 0 and len(emu.trace_any(empty, empty)) == 0
+
+
+def test_texture_coordinates_and_edge_configurations(emu, path_scene):
+    """Per-corner texture coordinates (they set dpdu, hence the frame BSDF samples are drawn in; one triangle with degenerate
+    coordinates), a scene without lights, depth 0, one sample per pixel and pass sizes that do not divide the sample count."""
+    rs = np.random.RandomState(11)
+    uv = rs.uniform(0, 1, (path_scene.n_prims, 6)).astype(np.float32)
+    uv[3] = [0.5, 0.5, 0.5, 0.5, 0.5, 0.5]
+    textured = replace(path_scene, tri_uv=uv)
+    cfg = path_scene.config.with_resolution(40, 30, spp=5)
+    emu.upload_scene(textured)
+    emu.set_camera(cfg)
+    kw = dict(rng_mode=RT_RNG_COUNTER, seed=4, max_depth=5)
+    got = emu.render(integrator=RT_INTEGRATOR_PATH, **kw)
+    _check_path(got, _oracle_path(Oracle(textured, cfg), **kw), "texture coordinates")
+    dark = replace(path_scene, light_id=np.full(path_scene.n_prims, -1, np.int32), lights=path_scene.lights[:0])
+    emu.upload_scene(dark)
+    emu.set_camera(cfg)
+    for integrator in (RT_INTEGRATOR_PATH, RT_INTEGRATOR_WHITTED):
+        rgb, w = emu.render(integrator=integrator, rng_mode=RT_RNG_COUNTER, max_depth=5)
+        assert not rgb.any() and (w == 5).all()
+    orc = Oracle(path_scene, cfg)
+    emu.upload_scene(path_scene)
+    emu.set_camera(cfg)
+    assert (got[0] != emu.render(integrator=RT_INTEGRATOR_PATH, **kw)[0]).any(axis=2).mean() > 0.3, "the coordinates matter"
+    for depth, spp in ((0, 5), (1, 1), (7, 5)):
+        want = _oracle_path(orc, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=depth, spp=spp)
+        for per_pass in (0, 2, 3):
+            _check_path(emu.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=depth, spp=spp, spp_per_pass=per_pass),
+                        want, f"depth {depth}, {spp} spp, passes of {per_pass}")
