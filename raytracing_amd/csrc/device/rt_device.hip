@@ -867,9 +867,10 @@ static int upload_scene_one(rt_context *c, const rt_scene_desc *d) {
         if (d->lights[i].prim_id < 0 || (uint32_t)d->lights[i].prim_id >= d->n_prims) return fail(c, RT_ERR_INVALID_ARG, "light prim_id out of range");
     for (uint32_t i = 0; i < d->n_materials; ++i)
         if (d->materials[i].type < RT_MAT_LAMBERTIAN || d->materials[i].type > RT_MAT_GLASS) return fail(c, RT_ERR_INVALID_ARG, "unknown material type");
-    // Depth of every node below the root (children have larger indices than their parent, so one forward pass fills it).
-    // An interior node at depth k can find k entries pending on the todo stack and push one more: the traversal keeps
-    // RT_STACK_TOTAL entries, like the reference's todo[64] (Accelerators/KDTree.cpp:396-398).
+    // Depth of every node below the root (children have larger indices than their parent, so one forward pass fills it;
+    // a node that several parents name, which no builder produces but the format can express, counts with its deepest
+    // parent). An interior node at depth k can find k entries pending on the todo stack and push one more: the traversal
+    // keeps RT_STACK_TOTAL entries, like the reference's todo[64] (Accelerators/KDTree.cpp:396-398).
     std::vector<uint8_t> depth(d->n_nodes, 0);
     for (uint32_t i = 0; i < d->n_nodes; ++i) {
         const uint32_t w0 = d->nodes[2 * i], w1 = d->nodes[2 * i + 1];
@@ -881,7 +882,9 @@ static int upload_scene_one(rt_context *c, const rt_scene_desc *d) {
             const uint32_t above = w1 >> 2;
             if (i + 1 >= d->n_nodes || above >= d->n_nodes || above <= i) return fail(c, RT_ERR_INVALID_ARG, "interior node child out of range");
             if (depth[i] >= RT_STACK_TOTAL) return fail(c, RT_ERR_INVALID_ARG, "KD-tree deeper than the 64-entry todo stack");
-            depth[i + 1] = depth[above] = (uint8_t)(depth[i] + 1);
+            const uint8_t below = (uint8_t)(depth[i] + 1);
+            depth[i + 1] = std::max(depth[i + 1], below);
+            depth[above] = std::max(depth[above], below);
         }
     }
     for (uint32_t i = 0; i < d->n_leaf_idx; ++i)

@@ -299,3 +299,65 @@ def test_texture_coordinates_and_edge_configurations(emu, path_scene):
         for per_pass in (0, 2, 3):
             _check_path(emu.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=3, max_depth=depth, spp=spp, spp_per_pass=per_pass),
                         want, f"depth {depth}, {spp} spp, passes of {per_pass}")
+
+
+def test_scene_tables_no_builder_would_produce(emu, path_scene):
+    """rt_upload_scene promises to validate everything a kernel will index with. Random node arrays that pass it - children
+    shared between parents, planes outside the bounds, infinite and NaN planes, empty and overlapping leaf ranges, leaves of
+    dozens of primitives - are traced under both schedules and rendered by both integrators: whatever the images show, no
+    access may leave a table or the stack and every launch must end. Arrays that break a rule must come back as errors."""
+    rs = np.random.RandomState(20)
+    n_prims = path_scene.n_prims
+    cfg = path_scene.config.with_resolution(24, 18, spp=1)
+    accepted = rejected = 0
+    for trial in range(40):
+        n_nodes = int(rs.randint(1, 120))
+        n_leaf_idx = int(rs.randint(0, 200))
+        leaf_idx = rs.randint(0, n_prims, n_leaf_idx).astype(np.int32)
+        nodes = np.zeros((n_nodes, 2), np.uint32)
+        breaks_a_rule = trial % 4 == 3
+        for i in range(n_nodes):
+            interior = i + 2 < n_nodes and rs.rand() < 0.6
+            if interior:
+                split = np.float32(rs.choice([rs.uniform(-100, 700), np.inf, -np.inf, np.nan, 0.0], p=[0.8, 0.05, 0.05, 0.05, 0.05]))
+                above = int(rs.randint(i + 1, n_nodes))
+                nodes[i] = (split.view(np.uint32), int(rs.randint(0, 3)) | (above << 2))
+            else:
+                count = int(rs.choice([0, 1, 1, 2, 5, 40]))
+                if count == 1:
+                    nodes[i] = (int(rs.randint(0, n_prims)), 3 | (1 << 2))
+                elif count > 1 and n_leaf_idx >= count:
+                    nodes[i] = (int(rs.randint(0, n_leaf_idx - count + 1)), 3 | (count << 2))
+                else:
+                    nodes[i] = (0, 3)
+        if breaks_a_rule:
+            kind = trial % 3
+            if kind == 0:
+                nodes[-1] = (n_prims + int(rs.randint(0, 5)), 3 | (1 << 2))               # primitive index past the list
+            elif kind == 1:
+                nodes[-1] = (max(0, n_leaf_idx - 1), 3 | (3 << 2))                         # index range past the list
+            else:
+                nodes[0] = (0, 0 | (0 << 2)) if n_nodes > 2 else (n_prims, 3 | (1 << 2))   # interior node naming itself
+        s = copy.copy(path_scene)
+        s.nodes, s.leaf_idx = nodes, leaf_idx
+        try:
+            emu.upload_scene(s)
+        except EmuError as e:
+            assert "rt error" in str(e), e
+            rejected += 1
+            continue
+        assert not breaks_a_rule, f"trial {trial} should have been refused"
+        accepted += 1
+        emu.set_camera(cfg)
+        o, d = raygen.incoherent_rays(path_scene.bounds, 96, seed=trial)
+        for schedule in ("lockstep", "stream"):
+            emu.set_trace_schedule(schedule)
+            prim, t, _ = emu.trace_closest(o, d)
+            assert ((prim >= -1) & (prim < n_prims)).all()
+            emu.trace_any(o, d, np.full(len(o), 300.0, np.float32))
+        emu.set_trace_schedule("auto")
+        for integrator, rng_mode in ((RT_INTEGRATOR_PATH, RT_RNG_COUNTER), (RT_INTEGRATOR_WHITTED, RT_RNG_REFERENCE_TILE_STREAM)):
+            rgb, w = emu.render(integrator=integrator, rng_mode=rng_mode, max_depth=3)
+            assert (w == 1).all()
+    assert accepted >= 25 and rejected >= 8
+    emu.upload_scene(path_scene)
