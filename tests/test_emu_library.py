@@ -361,3 +361,46 @@ def test_scene_tables_no_builder_would_produce(emu, path_scene):
             assert (w == 1).all()
     assert accepted >= 25 and rejected >= 8
     emu.upload_scene(path_scene)
+
+
+def test_calls_out_of_order_and_bad_arguments(path_scene):
+    """A fresh context: work before a scene or a camera exists, sizes and ranges that make no sense, more members than the
+    device list can name - errors, never a crash, and a clean teardown afterwards."""
+    if build_server() is None:
+        pytest.skip("no g++")
+    cfg = path_scene.config.with_resolution(16, 12, spp=2)
+    o, d = raygen.incoherent_rays(path_scene.bounds, 8, seed=1)
+    with pytest.raises(EmuError, match="rt error"):
+        EmuContext(device_ids=(0, 1))          # the stand-in runtime has one device
+    with pytest.raises(EmuError, match="rt error"):
+        EmuContext(device_ids=())
+    with EmuContext() as ctx:
+        with pytest.raises(EmuError, match="rt error"):
+            ctx.trace_closest(o, d)            # no scene
+        ctx.config = cfg
+        with pytest.raises(EmuError):
+            ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER)   # no scene, no camera
+        ctx.upload_scene(replace(path_scene, config=None))
+        with pytest.raises(EmuError, match="rt error"):
+            ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, spp=1, max_depth=2)   # no camera
+        ctx.set_camera(cfg)
+        for bad in (dict(spp=0), dict(spp=2, spp_begin=2, spp_end=1), dict(spp=2, spp_end=3), dict(spp=2, max_depth=-1), dict(spp=2, rng_mode=7),
+                    dict(spp=2, integrator=5)):
+            kw = dict(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=3)
+            kw.update(bad)
+            with pytest.raises(EmuError, match="rt error"):
+                ctx.render(**kw)
+        with pytest.raises(EmuError, match="rt error"):
+            ctx.render_noalloc(integrator=RT_INTEGRATOR_WHITTED, rng_mode=RT_RNG_REFERENCE_TILE_STREAM, spp=2, max_depth=3)   # counter streams only
+        with pytest.raises(EmuError, match="rt error"):
+            ctx.set_pipelines(9)
+        rgb, w = ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=3)   # and it still works
+        assert (w == 2).all() and rgb.max() > 0
+        ctx.set_camera(path_scene.config.with_resolution(600, 500, spp=1))   # 300 000 pixels: past the scratch array's 262 144
+        with pytest.raises(EmuError, match="rt error"):
+            ctx.render_noalloc(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=3)
+        ctx.set_camera(cfg)
+        with pytest.raises(EmuError, match="rt error"):
+            ctx.render_noalloc(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=65)
+        rgb2, w2 = ctx.render_noalloc(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=3)
+        assert np.array_equal(rgb2, rgb) and np.array_equal(w2, w)
