@@ -45,12 +45,17 @@ def _f32(a):
 
 
 class EmuContext:
-    def __init__(self, device_ids=(0,)):
+    def __init__(self, device_ids=(0,), lazy_streams=False):
+        """lazy_streams: queued work runs only when something waits for it (stream synchronize, an event another stream waits
+        for, a release), so work on different streams is reordered as far as the library's events allow."""
         exe = build_server()
         if exe is None:
             raise EmuError("no g++ to build the emulated library with")
         self._err = open(os.path.join(BIN, f"emu_library_{os.getpid()}_{id(self)}.stderr"), "w+")
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1")
+        env.pop("EMU_LAZY_STREAMS", None)
+        if lazy_streams:
+            env["EMU_LAZY_STREAMS"] = "1"
         self._p = subprocess.Popen([exe], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=self._err, env=env)
         self.config = None
         self._call(1, struct.pack("<i", len(device_ids)) + np.asarray(device_ids, np.int32).tobytes())

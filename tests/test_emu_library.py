@@ -4,7 +4,8 @@ memory is the heap at exact sizes, streams run in order, every launch runs its g
 barriers. The tests below are small versions of the GPU parity tests and compare with the oracle to the same bars: ids /
 t / barycentrics / occlusion bit-equal, Path film bit-equal (correctly rounded trig on both sides) up to reordered sums
 where several passes or members meet, Whitted within 1e-4 per pixel. One server process serves the whole module, so what
-a call leaves behind (buffers, counters, options) meets the next call, as in a host program.
+a call leaves behind (buffers, counters, options) meets the next call, as in a host program. The module runs twice: with
+streams that run their work as it is queued, and with streams that defer it until something waits for it.
 The library has no CPU path; this is a checker of its source (memory safety of host and device code, barrier discipline,
 buffer lifetimes across calls), run where no GPU is needed."""
 import copy
@@ -41,11 +42,13 @@ def _oracle_path(orc, **kw):
     return _oracle(orc, integrator=RT_INTEGRATOR_PATH, **kw)
 
 
-@pytest.fixture(scope="module")
-def emu():
+@pytest.fixture(scope="module", params=["eager", "lazy"])
+def emu(request):
+    """eager: queued work runs at once. lazy: it runs when something waits for it, which reorders the work of the context's
+    streams as far as the library's events allow - a missing event or synchronize shows as stale data."""
     if build_server() is None:
         pytest.skip("no g++")
-    ctx = EmuContext()
+    ctx = EmuContext(lazy_streams=request.param == "lazy")
     yield ctx
     ctx.close()   # raises on a sanitizer report, leaks included
 
@@ -134,7 +137,7 @@ def test_group_of_two_members():
     orc = Oracle(base, cfg)
     kw = dict(rng_mode=RT_RNG_COUNTER, seed=3, max_depth=5, spp=5)
     want = _oracle_path(orc, **kw)
-    with EmuContext(device_ids=(0, 0)) as grp:
+    with EmuContext(device_ids=(0, 0), lazy_streams=True) as grp:
         grp.upload_scene(base)
         grp.set_camera(cfg)
         grp.reset_stats()
@@ -374,7 +377,7 @@ def test_calls_out_of_order_and_bad_arguments(path_scene):
         EmuContext(device_ids=(0, 1))          # the stand-in runtime has one device
     with pytest.raises(EmuError, match="rt error"):
         EmuContext(device_ids=())
-    with EmuContext() as ctx:
+    with EmuContext(lazy_streams=True) as ctx:
         with pytest.raises(EmuError, match="rt error"):
             ctx.trace_closest(o, d)            # no scene
         ctx.config = cfg
