@@ -170,7 +170,9 @@ inline bool run_grid(Dim3 grid, Dim3 block, size_t ldsBytes, const std::function
     launch.gridDim_ = grid;
     launch.blockDim_ = block;
     std::unique_ptr<unsigned char[]> lds(new unsigned char[ldsBytes ? ldsBytes : 1]);
-    for (unsigned b = 0; b < grid.x; ++b) {
+    static const bool lastFirst = std::getenv("EMU_LAST_WORKGROUP_FIRST") != nullptr;   // a grid promises no order among workgroups
+    for (unsigned i = 0; i < grid.x; ++i) {
+        const unsigned b = lastFirst ? grid.x - 1 - i : i;
         launch.blockIdx_ = Dim3{b, 0, 0};
         for (size_t i = 0; i < ldsBytes; ++i) lds[i] = 0xCD;
         dynamicLds = lds.get();

@@ -54,8 +54,10 @@ class EmuContext:
         self._err = open(os.path.join(BIN, f"emu_library_{os.getpid()}_{id(self)}.stderr"), "w+")
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1")
         env.pop("EMU_LAZY_STREAMS", None)
-        if lazy_streams:
+        env.pop("EMU_LAST_WORKGROUP_FIRST", None)
+        if lazy_streams:   # the second schedule also runs the workgroups of every grid from the last to the first
             env["EMU_LAZY_STREAMS"] = "1"
+            env["EMU_LAST_WORKGROUP_FIRST"] = "1"
         self._p = subprocess.Popen([exe], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=self._err, env=env)
         self.config = None
         self._call(1, struct.pack("<i", len(device_ids)) + np.asarray(device_ids, np.int32).tobytes())
