@@ -16,9 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "bin")
 
 
-def build_server():
-    """g++ on tests/emu/emu_library.cpp (about 40 s); rebuilt when a source it includes is newer. None without g++."""
-    exe = os.path.join(BIN, "emu_library")
+def build_server(defines=(), suffix=""):
+    """g++ on tests/emu/emu_library.cpp (about a minute); rebuilt when a source it includes is newer. None without g++.
+    defines / suffix: a build of the library with other compile-time constants, kept beside the default one."""
+    exe = os.path.join(BIN, "emu_library" + suffix)
     emu = os.path.join(ROOT, "tests", "emu")
     dev = os.path.join(ROOT, "raytracing_amd", "csrc", "device")
     sources = [os.path.join(emu, n) for n in ("emu_library.cpp", "simt.h", os.path.join("hip", "hip_runtime.h"), os.path.join("rccl", "rccl.h"))]
@@ -29,7 +30,8 @@ def build_server():
         return None
     os.makedirs(BIN, exist_ok=True)
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-static-libasan", "-static-libubsan", "-fno-omit-frame-pointer", "-ffp-contract=off", "-Wall",
-           "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-variable", "-I" + emu, "-o", exe, sources[0], "-ldl", "-lpthread"]
+           "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-variable", *["-D" + d for d in defines], "-I" + emu, "-o", exe, sources[0], "-ldl",
+           "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building the emulated library failed:\n" + r.stderr[-3000:])
@@ -45,10 +47,10 @@ def _f32(a):
 
 
 class EmuContext:
-    def __init__(self, device_ids=(0,), lazy_streams=False):
+    def __init__(self, device_ids=(0,), lazy_streams=False, defines=(), suffix=""):
         """lazy_streams: queued work runs only when something waits for it (stream synchronize, an event another stream waits
         for, a release), so work on different streams is reordered as far as the library's events allow."""
-        exe = build_server()
+        exe = build_server(defines, suffix)
         if exe is None:
             raise EmuError("no g++ to build the emulated library with")
         self._err = open(os.path.join(BIN, f"emu_library_{os.getpid()}_{id(self)}.stderr"), "w+")

@@ -407,3 +407,31 @@ def test_calls_out_of_order_and_bad_arguments(path_scene):
             ctx.render_noalloc(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=65)
         rgb2, w2 = ctx.render_noalloc(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=3)
         assert np.array_equal(rgb2, rgb) and np.array_equal(w2, w)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("t_min", [1, 12])
+def test_merged_round_build_of_the_streaming_tracer(path_scene, t_min):
+    """The library built with RT_STREAM_MERGED=1 (dstream.h: every round serves node steps, leaf indices and primitive tests
+    behind one wait; off in the shipped build until it has been measured on a GPU): batch traces and the wavefront path
+    tracer's extend / shadow stages on a scene whose tables live in HBM, against the oracle. RT_SLOW=1 (another build)."""
+    if build_server() is None:
+        pytest.skip("no g++")
+    scene, cfg = raygen.grid_scene(32, 16, path_scene.config, width=W, height=H)
+    orc = Oracle(scene, cfg)
+    of, df = raygen.mesh_feature_rays(scene.tri_p[:-2], 900, seed=5)
+    oi, di = raygen.incoherent_rays(scene.bounds, 500, seed=3)
+    o, d = np.concatenate([of, oi]), np.concatenate([df, di])
+    with EmuContext(lazy_streams=True, defines=("RT_STREAM_MERGED=1", f"RT_MERGED_T_MIN={t_min}"), suffix=f"_merged{t_min}") as ctx:
+        ctx.upload_scene(scene)
+        ctx.set_camera(cfg)
+        assert ctx.stats()["scene_in_lds"] == 0
+        _check_traces(ctx, orc, o, d, np.random.RandomState(2).uniform(0, 400, len(o)).astype(np.float32), "merged rounds")
+        kw = dict(rng_mode=RT_RNG_COUNTER, seed=3, max_depth=6, spp=4)
+        ctx.reset_stats()
+        got = ctx.render(integrator=RT_INTEGRATOR_PATH, collect_stats=True, spp_per_pass=3, **kw)
+        st = ctx.stats()
+        want = _oracle_path(orc, collect_stats=True, **kw)
+        _check_path(got, want, "path, merged rounds")
+        assert st["rays_closest"] == want[2]["rays_closest"] and st["rays_any"] == want[2]["rays_any"]
+        assert st["n_tri_tests"] == want[2]["n_tri_tests"] and st["n_interior"] == want[2]["n_interior"] and st["n_leaf_idx"] == want[2]["n_leaf_idx"]
