@@ -186,7 +186,8 @@ int main(int argc, char **argv) {
            (stream && !ldsScene && RT_STREAM_MERGED) ? " (merged rounds)" : "", simt::waveOps);
     if (getenv("EMU_OPS_BY_LINE"))
         for (const auto &kv : simt::opsAtLine)
-            printf("  dstream.h:%d%s  %llu\n", kv.first < 0 ? -kv.first : kv.first, kv.first < 0 ? " (barrier)" : "", kv.second);
+            printf("  dstream.h:%d%s  %llu  mean lanes with a true predicate %.1f\n", kv.first < 0 ? -kv.first : kv.first, kv.first < 0 ? " (barrier)" : "",
+                   kv.second, (double)simt::lanesAtLine[kv.first] / (double)kv.second);
     free((void *)sc.nodes); free((void *)sc.leafIdx); free((void *)sc.triHot);
     return 0;
 }

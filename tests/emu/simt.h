@@ -44,6 +44,7 @@ inline ucontext_t scheduler;
 inline std::function<void()> *body = nullptr;
 inline unsigned long long waveOps = 0;                  // wave-wide operations evaluated so far
 inline std::map<int, unsigned long long> opsAtLine;     // the same by source line (negative: wave barriers)
+inline std::map<int, unsigned long long> lanesAtLine;   // lanes whose predicate was true, summed over the ballots of a line
 inline std::vector<std::unique_ptr<char[]>> stacks;     // fibre stacks, kept between workgroups
 inline unsigned char *dynamicLds = nullptr;             // the running workgroup's dynamic LDS
 
@@ -126,6 +127,7 @@ inline bool run_items(unsigned first, unsigned count, std::function<void()> fn, 
             }
             ++waveOps;
             ++opsAtLine[at];
+            lanesAtLine[at] += (unsigned long long)__builtin_popcountll(mask);
             progressed = true;
             if (++ops > maxOps) {
                 std::fprintf(stderr, "simt: work-items still running after %llu wave-wide operations\n", ops);

@@ -62,7 +62,15 @@ class EmuContext:
             env["EMU_LAST_WORKGROUP_FIRST"] = "1"
         self._p = subprocess.Popen([exe], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=self._err, env=env)
         self.config = None
-        self._call(1, struct.pack("<i", len(device_ids)) + np.asarray(device_ids, np.int32).tobytes())
+        try:
+            self._call(1, struct.pack("<i", len(device_ids)) + np.asarray(device_ids, np.int32).tobytes())
+        except EmuError:
+            self._p.kill()
+            self._p.wait()
+            self._p = None
+            self._err.close()
+            os.unlink(self._err.name)
+            raise
 
     # -- transport -----------------------------------------------------------------------------------------------------
     def _stderr(self):
@@ -88,7 +96,7 @@ class EmuContext:
 
     def close(self):
         """rt_destroy, then the end of the process: raises when a sanitizer had something to say."""
-        if self._p is None:
+        if getattr(self, "_p", None) is None:
             return
         p, self._p = self._p, None
         try:

@@ -26,7 +26,9 @@ def main():
     flatbin.write_scene(tmp + "/s.bin", scene, cfg, RT_INTEGRATOR_PATH, 1, 5, RT_RNG_COUNTER, 1)
     flatbin.write_rays(tmp + "/r.bin", o, d)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", EMU_OPS_BY_LINE="1")
-    for exe in ("emu_trace_m0", "emu_trace_m1"):
+    for exe in ("emu_trace_m0", "emu_trace_m1", "emu_trace_m1t12"):
+        if not os.path.exists(os.path.join(ROOT, "tests", "bin", exe)):
+            continue
         r = subprocess.run([os.path.join(ROOT, "tests", "bin", exe), tmp + "/s.bin", tmp + "/r.bin", tmp + "/o.bin", "stream", "1", "40"],
                            capture_output=True, text=True, env=env)
         print(exe, r.returncode, r.stdout.strip(), r.stderr.strip()[-500:])
