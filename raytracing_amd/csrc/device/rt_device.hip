@@ -734,8 +734,14 @@ int render_group(rt_context *c, const rt_render_params *p, float *rgb, float *ws
         NCCLCHK(c, g_rccl.GroupStart());
         for (int k = 0; k < G; ++k) {
             rt_context *m = members[k];
-            HIPCHK(c, hipSetDevice(m->device));
-            NCCLCHK(c, g_rccl.Reduce(m->dGroupFilm, m->dGroupFilm, nPix * 4, ncclFloat, ncclSum, 0, c->comms[k], m->stream));
+            ncclResult_t r = hipSetDevice(m->device) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+            if (r == ncclSuccess) r = g_rccl.Reduce(m->dGroupFilm, m->dGroupFilm, nPix * 4, ncclFloat, ncclSum, 0, c->comms[k], m->stream);
+            if (r != ncclSuccess) {
+                (void)g_rccl.GroupEnd();   // a group that was started is ended, whatever happened inside it
+                (void)hipSetDevice(c->device);
+                c->err = std::string("ncclReduce of member ") + std::to_string(k) + ": " + g_rccl.GetErrorString(r);
+                return RT_ERR_HIP;
+            }
         }
         NCCLCHK(c, g_rccl.GroupEnd());
         HIPCHK(c, hipSetDevice(c->device));

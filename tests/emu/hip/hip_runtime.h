@@ -117,10 +117,12 @@ namespace emu_rt {
 inline hipError_t lastError = hipSuccess;
 inline int workgroupsPerCU = 2;   // what the occupancy query answers
 inline int computeUnits = 2;      // what the device properties say: persistent grids stay small
+inline int devices = 2;           // device memory is the heap for all of them; a stream does not remember its device
 inline const bool lazy = std::getenv("EMU_LAZY_STREAMS") != nullptr;
 inline EmuStream nullStream{1};
 inline std::vector<EmuStream *> streams{&nullStream};
 inline unsigned long long recordCalls = 0;
+inline std::vector<EmuEvent *> retired;   // events the RCCL stand-in created; released once every stream is empty
 inline std::set<unsigned long long> recordsDone;   // record calls that have run: a wait names one call, not the event's latest
 inline bool done(unsigned long long seq) { return seq == 0 || recordsDone.count(seq) != 0; }
 
@@ -154,6 +156,8 @@ inline void run_until(EmuStream *s, unsigned long long seq) {
 inline void drain(EmuStream *s) { run_until(s, 0); }
 inline void drain_all() {
     for (size_t i = 0; i < streams.size(); ++i) drain(streams[i]);
+    for (EmuEvent *e : retired) delete e;
+    retired.clear();
 }
 inline void submit(hipStream_t stream, EmuItem item) {
     EmuStream *s = real(stream);
@@ -174,10 +178,10 @@ static inline const char *hipGetErrorString(hipError_t e) {
     return "unknown error";
 }
 static inline hipError_t hipGetLastError() { const hipError_t e = emu_rt::lastError; emu_rt::lastError = hipSuccess; return e; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = emu_rt::devices; return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < emu_rt::devices ? hipSuccess : hipErrorInvalidDevice; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d) {
-    if (d != 0) return hipErrorInvalidDevice;
+    if (d < 0 || d >= emu_rt::devices) return hipErrorInvalidDevice;
     std::memset(p, 0, sizeof *p);
     std::strcpy(p->name, "emulated");
     p->multiProcessorCount = emu_rt::computeUnits;

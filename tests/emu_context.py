@@ -47,7 +47,7 @@ def _f32(a):
 
 
 class EmuContext:
-    def __init__(self, device_ids=(0,), lazy_streams=False, defines=(), suffix=""):
+    def __init__(self, device_ids=(0,), lazy_streams=False, defines=(), suffix="", extra_env=None):
         """lazy_streams: queued work runs only when something waits for it (stream synchronize, an event another stream waits
         for, a release), so work on different streams is reordered as far as the library's events allow."""
         exe = build_server(defines, suffix)
@@ -60,6 +60,7 @@ class EmuContext:
         if lazy_streams:   # the second schedule also runs the workgroups of every grid from the last to the first
             env["EMU_LAZY_STREAMS"] = "1"
             env["EMU_LAST_WORKGROUP_FIRST"] = "1"
+        env.update(extra_env or {})
         self._p = subprocess.Popen([exe], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=self._err, env=env)
         self.config = None
         try:

@@ -126,9 +126,13 @@ def test_session_one_device(emu, path_scene, scene_name):
     assert rgb8.shape == (H, W, 3) and rgb8.max() > 40
 
 
-def test_group_of_two_members():
-    """rt_create_multi with the device listed twice: members' films summed on the device; a tile-stream Whitted job (member
-    0 alone, allocates) between two group jobs; teardown of both members."""
+@pytest.mark.parametrize("device_ids", [(0, 0), (0, 1), (1, 0, 1)])
+def test_group_of_members(device_ids):
+    """rt_create_multi. The device listed twice: members' films summed by a kernel on that device. Distinct devices: the
+    RCCL branch - communicator from ncclCommInitAll, one ncclReduce per member inside a group, on the member's stream -
+    against tests/emu/rccl/rccl.h, which gives the six entry points the library binds the semantics of a sum-reduce to rank
+    0. (1, 0, 1) names a device twice among three members: RCCL refuses that list, and so must rt_create_multi... by falling
+    back to the device-local sums. A tile-stream Whitted job (member 0 alone, allocates) sits between two group jobs."""
     from raytracing_amd.scene import FlatScene
     if build_server() is None:
         pytest.skip("no g++")
@@ -137,7 +141,7 @@ def test_group_of_two_members():
     orc = Oracle(base, cfg)
     kw = dict(rng_mode=RT_RNG_COUNTER, seed=3, max_depth=5, spp=5)
     want = _oracle_path(orc, **kw)
-    with EmuContext(device_ids=(0, 0), lazy_streams=True) as grp:
+    with EmuContext(device_ids=device_ids, lazy_streams=True) as grp:
         grp.upload_scene(base)
         grp.set_camera(cfg)
         grp.reset_stats()
@@ -374,7 +378,7 @@ def test_calls_out_of_order_and_bad_arguments(path_scene):
     cfg = path_scene.config.with_resolution(16, 12, spp=2)
     o, d = raygen.incoherent_rays(path_scene.bounds, 8, seed=1)
     with pytest.raises(EmuError, match="rt error"):
-        EmuContext(device_ids=(0, 1))          # the stand-in runtime has one device
+        EmuContext(device_ids=(0, 2))          # the stand-in runtime has two devices
     with pytest.raises(EmuError, match="rt error"):
         EmuContext(device_ids=())
     with EmuContext(lazy_streams=True) as ctx:
@@ -435,3 +439,18 @@ def test_merged_round_build_of_the_streaming_tracer(path_scene, t_min):
         _check_path(got, want, "path, merged rounds")
         assert st["rays_closest"] == want[2]["rays_closest"] and st["rays_any"] == want[2]["rays_any"]
         assert st["n_tri_tests"] == want[2]["n_tri_tests"] and st["n_interior"] == want[2]["n_interior"] and st["n_leaf_idx"] == want[2]["n_leaf_idx"]
+
+
+def test_a_failing_collective_is_an_error_not_a_crash(path_scene):
+    """ncclReduce returns an error (EMU_RCCL_REDUCE_FAILS makes the stand-in do so): rt_render reports it, the context can
+    still be used for work that needs no collective, and teardown is clean."""
+    if build_server() is None:
+        pytest.skip("no g++")
+    cfg = path_scene.config.with_resolution(24, 18, spp=4)
+    with EmuContext(device_ids=(0, 1), extra_env={"EMU_RCCL_REDUCE_FAILS": "1"}) as grp:
+        grp.upload_scene(path_scene)
+        grp.set_camera(cfg)
+        with pytest.raises(EmuError, match="ncclReduce of member 0"):
+            grp.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=3)
+        rgb, w = grp.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, max_depth=3, spp=1)   # fewer samples than members: member 0 alone
+        assert (w == 1).all()
