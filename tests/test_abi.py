@@ -81,6 +81,23 @@ def test_product_code_never_touches_the_oracle():
     assert "oracle" not in dev_rule
 
 
+def test_product_code_has_no_cpu_path_and_no_stand_ins():
+    """tests/emu compiles the library's sources for the CPU as a checker. Nothing of it may leak the other way: the package
+    never names the stand-in headers or their namespaces, the shipped library is built by hipcc for gfx950 alone, and its
+    only concessions are two macros with a device definition (a register pin, the dynamic LDS declaration)."""
+    pkg = os.path.join(ROOT, "raytracing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for word in ("simt::", "emu_rt", "emu_rccl", "tests/emu", "EMU_"):
+                    assert word not in text, f"{os.path.join(dirpath, f)} mentions {word}"
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    dev_rule = mk[mk.index("raytracing_amd/lib/libraytracing_amd.so:"):mk.index("oracle/liboracle.so:")]
+    assert "$(HIPCC)" in dev_rule and "emu" not in dev_rule
+    assert "--offload-arch=gfx950" in mk[mk.index("HIPFLAGS ="):mk.index("HOST_SRC")]
+
+
 def test_device_trig_helpers_are_correctly_rounded():
     """The kernels evaluate cos / sin in double and round once (the reference calls libm's cosf / sinf, whose last
     bit is implementation-defined). The helpers are host-callable: compare them with numpy's double results rounded
