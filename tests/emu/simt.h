@@ -93,7 +93,11 @@ inline bool run_items(unsigned first, unsigned count, std::function<void()> fn, 
     for (;;) {
         bool progressed = false;
         unsigned live = 0;
-        for (unsigned l = 0; l < count; ++l) {
+        // between two synchronising operations the order in which lanes run must not matter: the second schedule runs them
+        // from the last to the first
+        static const bool lastFirst = std::getenv("EMU_LAST_WORKGROUP_FIRST") != nullptr;
+        for (unsigned i = 0; i < count; ++i) {
+            const unsigned l = lastFirst ? count - 1 - i : i;
             if (lanes[l].done) continue;
             if (lanes[l].waitingAt == 0) {
                 current = &lanes[l];
