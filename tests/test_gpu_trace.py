@@ -10,7 +10,12 @@ from oracle_lib import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["lockstep", "stream"])
+import os
+
+SCHEDULES = ["lockstep", "stream"] + (["queue"] if os.environ.get("RT_TEST_QUEUE") == "1" else [])
+
+
+@pytest.fixture(autouse=True, params=SCHEDULES)
 def trace_schedule(request, gpu_ctx):
     """Every test of this module runs under both ray-to-lane schedules of the batch tracers."""
     gpu_ctx.set_trace_schedule(request.param)

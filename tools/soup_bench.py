@@ -69,10 +69,9 @@ def measure(scene, cfg, label, n, reps, depth):
         d = torch.tensor(d_np, device=dev)
         out = {"workload": f"{label}, {name} rays", "n_rays": n,
                "per_ray": {"interior": ni, "leaf": nl, "leaf_idx": nidx, "tri_tests": ntri}, "bytes_per_ray": bpr}
-        for stream in [sch == "stream" for sch in schedules]:
-            ctx.set_trace_schedule("stream" if stream else "lockstep")
+        for key in schedules:
+            ctx.set_trace_schedule(key)
             dt = timed(lambda: ctx.trace_closest_dev(n, o.data_ptr(), d.data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr()))
-            key = "stream" if stream else "lockstep"
             out[key] = {"Mrays_per_s": n / dt / 1e6, "ms": dt * 1e3, "achieved_GBs": bpr * n / dt / 1e9,
                         "frac_of_hbm_peak": bpr * n / dt / 1e9 / HBM_PEAK_GBS}
         ctx.set_trace_schedule("auto")

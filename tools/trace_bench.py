@@ -41,19 +41,24 @@ def main():
         ctx.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    def run(name, o, d, schedules=(False, True)):
+    all_schedules = tuple(os.environ.get("RT_TB_SCHEDULES", "lockstep,stream,queue").split(","))
+    quick = os.environ.get("RT_TB_QUICK") == "1"   # only the ungrouped batches
+
+    def run(name, o, d, schedules=None):
+        if quick and ("/" in name):
+            return
         o = o.contiguous()
         d = d.contiguous()
         torch.cuda.synchronize()
-        for stream in schedules:
-            ctx.set_trace_schedule("stream" if stream else "lockstep")
-            run1(name + (" stream" if stream else " lockstep"), o, d)
+        for sch in (schedules or all_schedules):
+            ctx.set_trace_schedule(sch)
+            run1(name + " " + sch, o, d)
 
     def run1(name, o, d):
         dt = timed(lambda: ctx.trace_closest_dev(n, o.data_ptr(), d.data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr()))
         da = timed(lambda: ctx.trace_any_dev(n, o.data_ptr(), d.data_ptr(), 0, occ.data_ptr()))
         ctx.synchronize()
-        print(f"{name:>16}: closest {n / dt / 1e9:7.2f} Grays/s ({dt * 1e3:7.3f} ms)   any {n / da / 1e9:7.2f} Grays/s   "
+        print(f"{name:>22}: closest {n / dt / 1e9:7.2f} Grays/s ({dt * 1e3:7.3f} ms)   any {n / da / 1e9:7.2f} Grays/s   "
               f"hit {float((prim >= 0).float().mean()):.3f} checksum {int(prim.long().sum())} {float(t[prim >= 0].double().sum()):.6e}")
 
     # camera rays in pixel order (pinhole at the camera position; directions through a regular grid)
@@ -96,10 +101,10 @@ def main():
     idx = torch.arange(n, device=dev)
     for w in (256, 1024, 4096):
         order = torch.sort((idx // w) * 8 + octant, stable=True).indices
-        run(f"inward/oct{w}", p[order], dhemi[order], schedules=(False,))
+        run(f"inward/oct{w}", p[order], dhemi[order], schedules=("lockstep",))
     major = torch.argmax(dhemi.abs(), dim=1).int()
     order = torch.sort(octant * 3 + major, stable=True).indices
-    run("inward/oct+axis", p[order], dhemi[order], schedules=(False,))
+    run("inward/oct+axis", p[order], dhemi[order], schedules=("lockstep",))
 
     # what the path tracer's second bounce traces: hits only (compacted, pixel order), cosine-distributed about the
     # surface normal that faces the incoming ray
@@ -122,12 +127,12 @@ def main():
     start_prim = prim[hitmask][reps_idx].clone()
     oc, dc = ph[reps_idx], dcos[reps_idx]
     order = torch.sort(start_prim, stable=True).indices
-    run("cosine/prim", oc[order], dc[order], schedules=(False,))
+    run("cosine/prim", oc[order], dc[order], schedules=("lockstep",))
     octc = (dc[:, 0] > 0).int() + 2 * (dc[:, 1] > 0).int() + 4 * (dc[:, 2] > 0).int()
     order = torch.sort(start_prim * 8 + octc, stable=True).indices
-    run("cosine/prim+oct", oc[order], dc[order], schedules=(False,))
+    run("cosine/prim+oct", oc[order], dc[order], schedules=("lockstep",))
     order = torch.sort(octc, stable=True).indices
-    run("cosine/oct", oc[order], dc[order], schedules=(False,))
+    run("cosine/oct", oc[order], dc[order], schedules=("lockstep",))
     # third bounce: from the hit points of those, again cosine-distributed
     ctx.set_trace_schedule("lockstep")
     o2, d2 = ph[reps_idx].contiguous(), dcos[reps_idx].contiguous()
