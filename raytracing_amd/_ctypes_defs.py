@@ -75,7 +75,6 @@ class RtStats(C.Structure):
         ("extend_ms", C.c_double),
         ("extend_rays", C.c_uint64),
         ("render_ms", C.c_double),
-        ("queue_guard", C.c_uint64),
         ("shade_launches", C.c_uint64),
         ("shade_ms", C.c_double),
         ("queue_bytes_per_pipeline", C.c_uint64),

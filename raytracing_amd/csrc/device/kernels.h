@@ -3,14 +3,13 @@
 #pragma once
 #include "dshade.h"
 #include "dstream.h"
-#include "dqueue.h"
 
 // ---------------------------------------------------------------------------------------------------
 // device-side counters (one array per context)
 // ---------------------------------------------------------------------------------------------------
 enum {
     ST_RAYS_CLOSEST = 0, ST_RAYS_ANY, ST_CAMERA_SAMPLES, ST_INTERIOR, ST_LEAF, ST_LEAFIDX, ST_TRI, ST_COUNTED_RAYS,
-    ST_EXTEND_RAYS, ST_QUEUE_GUARD, ST_COUNT
+    ST_EXTEND_RAYS, ST_COUNT
 };
 
 struct CameraDev {
@@ -141,51 +140,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any_stream(DevScene sc, uint
     TraceAnyJob job = {o, d, tmax, occluded};
     trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16,
                                                                        (uint32_t)n, job, cn);
-    if (STATS) flush_counters(stats, cn, cn.rays);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
-}
-
-// Work-queue flavours (dqueue.h). Dynamic LDS: [4 wave blocks of ray slots and queues][scene tables]. `overflow` holds
-// gridDim.x * 4 regions of QueueLds::kOverflowPerWave todo entries.
-template <bool LDS_SCENE> struct QueueCfg {
-    static constexpr int R = LDS_SCENE ? 96 : RT_Q_SLOTS;
-    static constexpr int SL = LDS_SCENE ? 8 : RT_Q_STACK_LDS;
-    using Lds = QueueLds<R, SL>;
-};
-template <bool LDS_SCENE> RT_HD constexpr uint32_t queue_lds_bytes() { return QueueCfg<LDS_SCENE>::Lds::kBytesPerBlock; }
-template <bool LDS_SCENE> RT_HD constexpr uint32_t queue_overflow_entries_per_wave() { return QueueCfg<LDS_SCENE>::Lds::kOverflowPerWave; }
-
-template <bool CLOSEST, bool LDS_SCENE, bool STATS, bool SPH, class Job>
-RT_DEV void run_trace_queue(const DevScene &sc, uint4 *smem, uint2 *overflow, uint32_t n, Job &job, TravCounters &cn, unsigned long long *guard) {
-    using C = QueueCfg<LDS_SCENE>;
-    SceneTables tb;
-    tables_setup<LDS_SCENE>(sc, smem, tb, queue_lds_bytes<LDS_SCENE>());
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t *lds = reinterpret_cast<uint32_t *>(smem) + wave * C::Lds::kDwordsPerWave;
-    uint2 *ovf = overflow + (size_t)(blockIdx.x * (RT_BLOCK / 64) + wave) * C::Lds::kOverflowPerWave;
-    trace_queue<CLOSEST, STATS, LDS_SCENE, SPH, C::R, C::SL>(sc, tb, lds, ovf, n, job, cn, guard);
-}
-
-template <bool LDS_SCENE, bool STATS, bool SPH>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_queue(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
-                                                                  const float *__restrict__ tmax, int *__restrict__ prim, float *__restrict__ tOut,
-                                                                  float *__restrict__ bary, unsigned long long *stats, uint2 *overflow) {
-    RT_DYNAMIC_LDS(smem);
-    TravCounters cn = {0, 0, 0, 0, 0};
-    TraceClosestJob job = {o, d, tmax, prim, tOut, bary};
-    run_trace_queue<true, LDS_SCENE, STATS, SPH>(sc, smem, overflow, (uint32_t)n, job, cn, &stats[ST_QUEUE_GUARD]);
-    if (STATS) flush_counters(stats, cn, cn.rays);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
-}
-
-template <bool LDS_SCENE, bool STATS, bool SPH>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_any_queue(DevScene sc, uint64_t n, const float *__restrict__ o, const float *__restrict__ d,
-                                                              const float *__restrict__ tmax, uint8_t *__restrict__ occluded, unsigned long long *stats,
-                                                              uint2 *overflow) {
-    RT_DYNAMIC_LDS(smem);
-    TravCounters cn = {0, 0, 0, 0, 0};
-    TraceAnyJob job = {o, d, tmax, occluded};
-    run_trace_queue<false, LDS_SCENE, STATS, SPH>(sc, smem, overflow, (uint32_t)n, job, cn, &stats[ST_QUEUE_GUARD]);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }

@@ -129,8 +129,6 @@ struct rt_context {
     float *dGroupFilm = nullptr;            // packed film of this member: rgb sums (3 n) then weight sums (n)
     size_t groupFilmPixels = 0;
     hipEvent_t groupDone = nullptr;
-    uint2 *dQueueOverflow = nullptr;   // todo entries beyond the LDS part of the work-queue tracer, one region per resident wave
-    size_t queueOverflowEntries = 0;
     unsigned char *scratchPtr = nullptr;   // this GPU's copy of the static scratch array (rt_render_noalloc_dev)
     bool spillDirty = false;   // the last render returned an error: the spill buffers may hold its samples
     uint2 *dPixelState = nullptr;
@@ -330,36 +328,6 @@ void launch_stream(rt_context *c, K k, uint64_t n, Args... args) {
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, args...);
 }
 
-size_t queue_lds_bytes_of(const rt_context *c) { return c->ldsScene ? queue_lds_bytes<true>() + c->sc.ldsSceneBytes : queue_lds_bytes<false>(); }
-
-// Overflow region of the work-queue tracer for a grid of `blocks` workgroups (grows on demand, never shrinks).
-int ensure_queue_overflow(rt_context *c, int blocks) {
-    const size_t perWave = c->ldsScene ? queue_overflow_entries_per_wave<true>() : queue_overflow_entries_per_wave<false>();
-    const size_t need = (size_t)blocks * (RT_BLOCK / 64) * perWave;
-    if (c->queueOverflowEntries >= need) return RT_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->dQueueOverflow) (void)hipFree(c->dQueueOverflow);
-    c->dQueueOverflow = nullptr;
-    c->queueOverflowEntries = 0;
-    HIPCHK(c, hipMalloc((void **)&c->dQueueOverflow, need * sizeof(uint2)));
-    HIPCHK(c, hipMemsetAsync(c->dQueueOverflow, 0, need * sizeof(uint2), c->stream));   // entries are node indices: never start from foreign bits
-    c->queueOverflowEntries = need;
-    return RT_OK;
-}
-
-template <typename K, typename... Args>
-int launch_queue(rt_context *c, K k, uint64_t n, Args... args) {
-    const size_t lds = queue_lds_bytes_of(c);
-    // a wave holds up to RT_Q_SLOTS rays at a time: small batches get fewer workgroups, so that the waves that run are full
-    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 2 * RT_BLOCK - 1) / (2 * RT_BLOCK), (uint64_t)resident_grid(c, k, lds)));
-    const int rc = ensure_queue_overflow(c, grid);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, args..., c->dQueueOverflow);
-    return RT_OK;
-}
-
-bool use_queue_schedule(const rt_context *c) { return c->traceSchedule == RT_SCHEDULE_QUEUE; }
-
 bool use_stream_schedule(const rt_context *c) {
     return c->traceSchedule == RT_SCHEDULE_STREAM || (c->traceSchedule == RT_SCHEDULE_AUTO && !c->ldsScene);
 }
@@ -374,10 +342,7 @@ int trace_closest_dev(rt_context *c, uint64_t n, const float *o, const float *d,
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
         int32_t *prim_ = prim ? prim + base : nullptr;
         float *t_ = t ? t + base : nullptr, *bary_ = bary ? bary + 3 * base : nullptr;
-        if (use_queue_schedule(c)) {
-            const int rq = launch_queue(c, RT_PICK(k_trace_closest_queue, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
-            if (rq) return rq;
-        } else if (use_stream_schedule(c)) {
+        if (use_stream_schedule(c)) {
             launch_stream(c, RT_PICK(k_trace_closest_stream, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
         } else {
             launch_lockstep(c, RT_PICK(k_trace_closest, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
@@ -391,10 +356,7 @@ int trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, con
     for (uint64_t base = 0; base < n; base += kMaxRaysPerLaunch) {
         const uint64_t m = std::min<uint64_t>(kMaxRaysPerLaunch, n - base);
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
-        if (use_queue_schedule(c)) {
-            const int rq = launch_queue(c, RT_PICK(k_trace_any_queue, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
-            if (rq) return rq;
-        } else if (use_stream_schedule(c)) {
+        if (use_stream_schedule(c)) {
             launch_stream(c, RT_PICK(k_trace_any_stream, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
         } else {
             launch_lockstep(c, RT_PICK(k_trace_any, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
@@ -875,7 +837,6 @@ static void destroy_one(rt_context *c) {
     if (c->dWhittedOffsets) (void)hipFree(c->dWhittedOffsets);
     if (c->dWhittedDraws) (void)hipFree(c->dWhittedDraws);
     if (c->dGroupFilm) (void)hipFree(c->dGroupFilm);
-    if (c->dQueueOverflow) (void)hipFree(c->dQueueOverflow);
     if (c->groupDone) (void)hipEventDestroy(c->groupDone);
     for (auto *events : {&c->extendEvents, &c->shadeEvents})
         for (auto &ep : *events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -1283,8 +1244,7 @@ int rt_develop(rt_context *c, const float *rgb, const float *wsum, float film_sc
 static int set_option_one(rt_context *c, int option, int value) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (option == RT_OPTION_TRACE_SCHEDULE) {
-        if (value != RT_SCHEDULE_AUTO && value != RT_SCHEDULE_LOCKSTEP && value != RT_SCHEDULE_STREAM && value != RT_SCHEDULE_QUEUE)
-            return fail(c, RT_ERR_INVALID_ARG, "unknown trace schedule");
+        if (value != RT_SCHEDULE_AUTO && value != RT_SCHEDULE_LOCKSTEP && value != RT_SCHEDULE_STREAM) return fail(c, RT_ERR_INVALID_ARG, "unknown trace schedule");
         c->traceSchedule = value;
         return RT_OK;
     }
@@ -1312,7 +1272,6 @@ static int get_stats_one(rt_context *c, rt_stats *out) {
     out->n_tri_tests = h[ST_TRI];
     out->counted_rays = h[ST_COUNTED_RAYS];
     out->extend_rays = h[ST_EXTEND_RAYS];
-    out->queue_guard = h[ST_QUEUE_GUARD];
     const double ms = elapsed_ms(c->extendEvents, c->extendEventsUsed);
     out->extend_launches = c->extendEventsUsed;
     out->extend_ms = ms;

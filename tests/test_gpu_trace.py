@@ -10,12 +10,7 @@ from oracle_lib import Oracle
 pytestmark = pytest.mark.gpu
 
 
-import os
-
-SCHEDULES = ["lockstep", "stream"] + (["queue"] if os.environ.get("RT_TEST_QUEUE") == "1" else [])
-
-
-@pytest.fixture(autouse=True, params=SCHEDULES)
+@pytest.fixture(autouse=True, params=["lockstep", "stream"])
 def trace_schedule(request, gpu_ctx):
     """Every test of this module runs under both ray-to-lane schedules of the batch tracers."""
     gpu_ctx.set_trace_schedule(request.param)

@@ -41,7 +41,7 @@ def main():
         ctx.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    all_schedules = tuple(os.environ.get("RT_TB_SCHEDULES", "lockstep,stream,queue").split(","))
+    all_schedules = tuple(os.environ.get("RT_TB_SCHEDULES", "lockstep,stream").split(","))
     quick = os.environ.get("RT_TB_QUICK") == "1"   # only the ungrouped batches
 
     def run(name, o, d, schedules=None):
