@@ -217,7 +217,7 @@ int rt_trace_any(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d
  *                               scenes in HBM (1 M-triangle soup, incoherent rays: 0.63 vs 0.36 G rays/s).
  * Applies to rt_trace_* and, for scenes in HBM, to the extend and shadow stages of rt_render. */
 enum { RT_OPTION_TRACE_SCHEDULE = 1, RT_OPTION_PIPELINES = 2 };
-enum { RT_SCHEDULE_AUTO = 0, RT_SCHEDULE_LOCKSTEP = 1, RT_SCHEDULE_STREAM = 2 };
+enum { RT_SCHEDULE_AUTO = 0, RT_SCHEDULE_LOCKSTEP = 1, RT_SCHEDULE_STREAM = 2, RT_SCHEDULE_REFILL = 3 };
 /* RT_OPTION_PIPELINES: how many passes of the wavefront path tracer overlap on separate streams (1..RT_MAX_PIPELINES,
  * default RT_MAX_PIPELINES). 1 runs the passes one after the other, which is how a single kernel's launch time is
  * measured without other passes sharing the CUs. Results do not depend on it. */

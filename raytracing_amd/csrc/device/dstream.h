@@ -335,9 +335,10 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                     if (STATS) ++cn.leafIdx;
                 }
                 if (STATS) ++cn.tri;
-                const float4 q0 = tb.triHot[triBase + 3 * prim + 0];
-                const float4 q1 = tb.triHot[triBase + 3 * prim + 1];
-                const float4 q2 = tb.triHot[triBase + 3 * prim + 2];
+                const uint32_t rec = tri_record(triBase, prim);
+                const float4 q0 = tb.triHot[rec + 0];
+                const float4 q1 = tb.triHot[rec + 1];
+                const float4 q2 = tb.triHot[rec + 2];
                 float t, b0, b1, b2;
                 ++leafI;
                 bool accepted;

@@ -128,44 +128,58 @@ RT_DEV bool bounds_clip(const DevScene &sc, const RayCtx &r, float rayTMax, floa
 
 // Ray/triangle test. rayTMax is the ray's current m_tMax. PERM: the vertices come from the copy of the
 // table that is already permuted for this ray's kz.
+// Two floats that the compiler keeps in a register pair: +, - and * on them are the packed FP32 instructions (two IEEE
+// operations per issue slot, each rounded exactly as the scalar one).
+typedef float v2f __attribute__((vector_size(8)));
+RT_HD v2f mk2(float a, float b) { v2f r = {a, b}; return r; }
+
 template <bool PERM>
 RT_DEV bool tri_test(const RayCtx &r, f3 p0, f3 p1, f3 p2, float rayTMax, float &tOut, float &b0o, float &b1o, float &b2o) {
-    f3 p0t = (PERM ? p0 : perm3(p0, r.kz)) - r.op;
-    f3 p1t = (PERM ? p1 : perm3(p1, r.kz)) - r.op;
-    f3 p2t = (PERM ? p2 : perm3(p2, r.kz)) - r.op;
-    p0t.x += r.Sx * p0t.z; p0t.y += r.Sy * p0t.z;
-    p1t.x += r.Sx * p1t.z; p1t.y += r.Sy * p1t.z;
-    p2t.x += r.Sx * p2t.z; p2t.y += r.Sy * p2t.z;
-    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
-    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
-    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
-    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
-        double p2txp1ty = (double)p2t.x * (double)p1t.y;
-        double p2typ1tx = (double)p2t.y * (double)p1t.x;
+    const f3 q0 = PERM ? p0 : perm3(p0, r.kz), q1 = PERM ? p1 : perm3(p1, r.kz), q2 = PERM ? p2 : perm3(p2, r.kz);
+    // translate, shear, edge functions: x and y of a vertex travel as a pair. Every product and every sum is rounded once,
+    // in the order of the reference's scalar code (p.x += Sx * p.z; e0 = p1.x * p2.y - p1.y * p2.x ...).
+    const v2f oxy = mk2(r.op.x, r.op.y), sxy = mk2(r.Sx, r.Sy);
+    v2f a0 = mk2(q0.x, q0.y) - oxy, a1 = mk2(q1.x, q1.y) - oxy, a2 = mk2(q2.x, q2.y) - oxy;
+    float z0 = q0.z - r.op.z, z1 = q1.z - r.op.z, z2 = q2.z - r.op.z;
+    a0 = a0 + sxy * mk2(z0, z0);
+    a1 = a1 + sxy * mk2(z1, z1);
+    a2 = a2 + sxy * mk2(z2, z2);
+    const v2f m0 = a1 * mk2(a2[1], a2[0]), m1 = a2 * mk2(a0[1], a0[0]), m2 = a0 * mk2(a1[1], a1[0]);
+    float e0 = m0[0] - m0[1];
+    float e1 = m1[0] - m1[1];
+    float e2 = m2[0] - m2[1];
+    RT_PIN_VGPRS(e0, e1);   // three plain subtractions: pairing two of them would cost three register moves
+    // e0 == 0 || e1 == 0 || e2 == 0 (a NaN is not zero, and fminf skips it)
+    if (fminf(fminf(fabsf(e0), fabsf(e1)), fabsf(e2)) == 0.0f) {
+        double p2txp1ty = (double)a2[0] * (double)a1[1];
+        double p2typ1tx = (double)a2[1] * (double)a1[0];
         e0 = (float)(p2typ1tx - p2txp1ty);
-        double p0txp2ty = (double)p0t.x * (double)p2t.y;
-        double p0typ2tx = (double)p0t.y * (double)p2t.x;
+        double p0txp2ty = (double)a0[0] * (double)a2[1];
+        double p0typ2tx = (double)a0[1] * (double)a2[0];
         e1 = (float)(p0typ2tx - p0txp2ty);
-        double p1txp0ty = (double)p1t.x * (double)p0t.y;
-        double p1typ0tx = (double)p1t.y * (double)p0t.x;
+        double p1txp0ty = (double)a1[0] * (double)a0[1];
+        double p1typ0tx = (double)a1[1] * (double)a0[0];
         e2 = (float)(p1typ0tx - p1txp0ty);
     }
-    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    // (e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0): the smallest is negative and the largest positive
+    // (a NaN compares false in the reference's form; fminf / fmaxf skip it, and three NaNs give a NaN, which compares false)
+    const float eMin = fminf(fminf(e0, e1), e2), eMax = fmaxf(fmaxf(e0, e1), e2);
+    if ((eMin < 0) & (eMax > 0)) return false;
     float det = e0 + e1 + e2;
     if (det == 0) return false;
-    p0t.z *= r.Sz;
-    p1t.z *= r.Sz;
-    p2t.z *= r.Sz;
-    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    z0 *= r.Sz;
+    z1 *= r.Sz;
+    z2 *= r.Sz;
+    float tScaled = e0 * z0 + e1 * z1 + e2 * z2;
     if (det < 0 && (tScaled >= 0 || tScaled < rayTMax * det)) return false;
     else if (det > 0 && (tScaled <= 0 || tScaled > rayTMax * det)) return false;
     float invDet = 1 / det;
     float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
     float t = tScaled * invDet;
-    float maxZt = gmax(fabsf(p0t.z), gmax(fabsf(p1t.z), fabsf(p2t.z)));
+    float maxZt = gmax(fabsf(z0), gmax(fabsf(z1), fabsf(z2)));
     float deltaZ = gamma_err(3) * maxZt;
-    float maxXt = gmax(fabsf(p0t.x), gmax(fabsf(p1t.x), fabsf(p2t.x)));
-    float maxYt = gmax(fabsf(p0t.y), gmax(fabsf(p1t.y), fabsf(p2t.y)));
+    float maxXt = gmax(fabsf(a0[0]), gmax(fabsf(a1[0]), fabsf(a2[0])));
+    float maxYt = gmax(fabsf(a0[1]), gmax(fabsf(a1[1]), fabsf(a2[1])));
     float deltaX = gamma_err(5) * (maxXt + maxZt);
     float deltaY = gamma_err(5) * (maxYt + maxZt);
     float deltaE = 2 * (gamma_err(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
@@ -235,6 +249,10 @@ template <bool PERM> RT_DEV uint32_t tri_table_base(const DevScene &sc, int kz) 
     return PERM ? (uint32_t)(kz == 2 ? 0 : kz + 1) * sc.nPrims * 3u : 0u;
 }
 
+// Index of a primitive's first float4 in the triangle table: 32-bit shifts and adds (3 * prim as a multiply would be a
+// quarter-rate instruction, and 64-bit pointer arithmetic on a per-lane index costs as much).
+RT_DEV uint32_t tri_record(uint32_t triBase, int prim) { return triBase + (((uint32_t)prim << 1) + (uint32_t)prim); }
+
 // SPH: the scene has sphere primitives (scenes without them compile the sphere test away).
 template <bool CLOSEST, bool STATS, int SL, bool PERM, bool SPH>
 RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsStack, uint32_t tid, const RayCtx &r, float rayTMaxIn,
@@ -251,7 +269,7 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
     int sp = 0;
     uint32_t node = 0;
     bool found = false;
-    const float4 *tris = tb.triHot + tri_table_base<PERM>(sc, r.kz);
+    const uint32_t triBase = tri_table_base<PERM>(sc, r.kz);
     for (;;) {
         if (CLOSEST && rayTMax < tMin) break;
         uint2 nd = tb.nodes[node];
@@ -297,9 +315,10 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
                 if (STATS) ++cn.leafIdx;
             }
             if (STATS) ++cn.tri;
-            const float4 q0 = tris[3 * prim + 0];
-            const float4 q1 = tris[3 * prim + 1];
-            const float4 q2 = tris[3 * prim + 2];
+            const uint32_t rec = tri_record(triBase, prim);
+            const float4 q0 = tb.triHot[rec + 0];
+            const float4 q1 = tb.triHot[rec + 1];
+            const float4 q2 = tb.triHot[rec + 2];
             float t, b0, b1, b2;
             bool accepted;
             if (SPH && q0.w == RT_PRIM_SPHERE) {

@@ -3,6 +3,7 @@
 #pragma once
 #include "dshade.h"
 #include "dstream.h"
+#include "drefill.h"
 
 // ---------------------------------------------------------------------------------------------------
 // device-side counters (one array per context)
@@ -140,6 +141,40 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_any_stream(DevScene sc, uint
     TraceAnyJob job = {o, d, tmax, occluded};
     trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16,
                                                                        (uint32_t)n, job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
+}
+
+// Refilling flavours (drefill.h): the lockstep kernels' LDS layout and grid; a wave takes its rays 64 at a time, chunk c
+// by wave c mod the number of waves. n < 2^32.
+#ifndef RT_RF_MIN_BLOCKS
+#define RT_RF_MIN_BLOCKS 5   // workgroups per CU the register allocation of the refilling kernels is held to (8: spills; 4 and 6: slower)
+#endif
+template <bool LDS_SCENE, bool STATS, bool SPH>
+__global__ __launch_bounds__(RT_BLOCK, RT_RF_MIN_BLOCKS) void k_trace_closest_refill(DevScene sc, uint64_t n, const float *__restrict__ o,
+                                                                                     const float *__restrict__ d, const float *__restrict__ tmax,
+                                                                                     int *__restrict__ prim, float *__restrict__ tOut,
+                                                                                     float *__restrict__ bary, unsigned long long *stats) {
+    RT_DYNAMIC_LDS(smem);
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    TravCounters cn = {0, 0, 0, 0, 0};
+    TraceClosestJob job = {o, d, tmax, prim, tOut, bary};
+    trace_refill<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), (uint32_t)n, job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+}
+
+template <bool LDS_SCENE, bool STATS, bool SPH>
+__global__ __launch_bounds__(RT_BLOCK, RT_RF_MIN_BLOCKS) void k_trace_any_refill(DevScene sc, uint64_t n, const float *__restrict__ o,
+                                                                                 const float *__restrict__ d, const float *__restrict__ tmax,
+                                                                                 uint8_t *__restrict__ occluded, unsigned long long *stats) {
+    RT_DYNAMIC_LDS(smem);
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    TravCounters cn = {0, 0, 0, 0, 0};
+    TraceAnyJob job = {o, d, tmax, occluded};
+    trace_refill<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), (uint32_t)n, job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }
@@ -298,6 +333,27 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_stream(DevScene sc, const f
     ExtendJob job = {rayA, rayB, hit, commonOrigin};
     trace_stream<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
                                                                       job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+        atomicAdd(&stats[ST_EXTEND_RAYS], (unsigned long long)n);
+    }
+}
+
+// Refilling flavour of k_extend for scenes in LDS (drefill.h): same LDS layout and grid as k_extend.
+template <bool LDS_SCENE, bool STATS, bool SPH>
+__global__ __launch_bounds__(RT_BLOCK, RT_RF_MIN_BLOCKS) void k_extend_refill(DevScene sc, const float4 *__restrict__ rayA,
+                                                                              const float4 *__restrict__ rayB, float4 *__restrict__ hit,
+                                                                              const uint32_t *__restrict__ count, unsigned long long *stats,
+                                                                              float4 commonOrigin) {
+    RT_DYNAMIC_LDS(smem);
+    const uint32_t n = *count;
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    TravCounters cn = {0, 0, 0, 0, 0};
+    ExtendJob job = {rayA, rayB, hit, commonOrigin};
+    trace_refill<true, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), n, job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&stats[ST_RAYS_CLOSEST], (unsigned long long)n);
@@ -583,6 +639,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_stream(DevScene sc, PathBuf
     ShadowJob job = {pb.shA, pb.shB, pb.shC, pb.L};
     trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
                                                                        job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
+}
+
+template <bool LDS_SCENE, bool STATS, bool SPH>
+__global__ __launch_bounds__(RT_BLOCK, RT_RF_MIN_BLOCKS) void k_shadow_refill(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
+    RT_DYNAMIC_LDS(smem);
+    const uint32_t n = pb.counts[cnt_index(bounce, 1)];
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    TravCounters cn = {0, 0, 0, 0, 0};
+    ShadowJob job = {pb.shA, pb.shB, pb.shC, pb.L};
+    trace_refill<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), n, job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }

@@ -100,6 +100,8 @@ struct rt_context {
     // stats
     unsigned long long *dStats = nullptr;
     int traceSchedule = RT_SCHEDULE_AUTO;
+    // first bounce whose extend / shadow stage runs the refilling kernels (scenes in LDS); experiments set them from the environment
+    int refillExtendFrom = 1, refillShadowFrom = 1 << 30;
     int pipelines = RT_PIPES;   // RT_OPTION_PIPELINES
     std::vector<EventPair> extendEvents, shadeEvents;   // HIP events around every extend / shade launch of the path tracer
     size_t extendEventsUsed = 0, shadeEventsUsed = 0;
@@ -328,6 +330,15 @@ void launch_stream(rt_context *c, K k, uint64_t n, Args... args) {
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, args...);
 }
 
+// Refilling kernels: the lockstep kernels' LDS layout, and a grid that is resident as a whole (their waves split the rays
+// statically, as the streaming kernels do).
+template <typename K, typename... Args>
+void launch_refill(rt_context *c, K k, uint64_t n, Args... args) {
+    const size_t lds = trace_lds_bytes(c);
+    const int grid = (int)std::min<uint64_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)resident_grid(c, k, lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, args...);
+}
+
 bool use_stream_schedule(const rt_context *c) {
     return c->traceSchedule == RT_SCHEDULE_STREAM || (c->traceSchedule == RT_SCHEDULE_AUTO && !c->ldsScene);
 }
@@ -342,7 +353,9 @@ int trace_closest_dev(rt_context *c, uint64_t n, const float *o, const float *d,
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
         int32_t *prim_ = prim ? prim + base : nullptr;
         float *t_ = t ? t + base : nullptr, *bary_ = bary ? bary + 3 * base : nullptr;
-        if (use_stream_schedule(c)) {
+        if (c->traceSchedule == RT_SCHEDULE_REFILL) {
+            launch_refill(c, RT_PICK(k_trace_closest_refill, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
+        } else if (use_stream_schedule(c)) {
             launch_stream(c, RT_PICK(k_trace_closest_stream, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
         } else {
             launch_lockstep(c, RT_PICK(k_trace_closest, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
@@ -356,7 +369,9 @@ int trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, con
     for (uint64_t base = 0; base < n; base += kMaxRaysPerLaunch) {
         const uint64_t m = std::min<uint64_t>(kMaxRaysPerLaunch, n - base);
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
-        if (use_stream_schedule(c)) {
+        if (c->traceSchedule == RT_SCHEDULE_REFILL) {
+            launch_refill(c, RT_PICK(k_trace_any_refill, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
+        } else if (use_stream_schedule(c)) {
             launch_stream(c, RT_PICK(k_trace_any_stream, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
         } else {
             launch_lockstep(c, RT_PICK(k_trace_any, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
@@ -470,6 +485,10 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
                 auto kx = RT_PICK(k_extend_stream, c, stats);
                 hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, originsOf(b),
                                    (const float4 *)pb.rayB[cur], pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], rs.stats, camOrigin);
+            } else if (c->ldsScene && b >= c->refillExtendFrom) {
+                auto kx = RT_PICK(k_extend_refill, c, stats);
+                hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, lds)), dim3(RT_BLOCK), lds, st, c->sc, originsOf(b), (const float4 *)pb.rayB[cur], pb.hit,
+                                   (const uint32_t *)&pb.counts[cnt_index(b, 0)], rs.stats, camOrigin);
             } else {
                 auto kx = RT_PICK(k_extend, c, stats);
                 hipLaunchKernelGGL(kx, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, originsOf(b), (const float4 *)pb.rayB[cur], pb.hit,
@@ -486,6 +505,9 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
                 if (streamTrace) {
                     auto ks = RT_PICK(k_shadow_stream, c, stats);
                     hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, pb, b, rs.stats);
+                } else if (c->ldsScene && b >= c->refillShadowFrom) {
+                    auto ks = RT_PICK(k_shadow_refill, c, stats);
+                    hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, lds)), dim3(RT_BLOCK), lds, st, c->sc, pb, b, rs.stats);
                 } else {
                     auto ks = RT_PICK(k_shadow, c, stats);
                     hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, rs.stats);
@@ -805,6 +827,8 @@ int rt_create(int device_id, rt_context **out) {
 #define RT_GRID_BLOCKS_PER_CU 8   // persistent grids: workgroups per CU (grid-stride loops over the device-resident queue counters)
 #endif
     c->gridBlocks = c->numCUs * RT_GRID_BLOCKS_PER_CU;
+    if (const char *v = std::getenv("RT_EXP_REFILL_EXTEND_FROM")) c->refillExtendFrom = std::atoi(v);
+    if (const char *v = std::getenv("RT_EXP_REFILL_SHADOW_FROM")) c->refillShadowFrom = std::atoi(v);
     if ((e = scratch_address(device_id, &c->scratchPtr)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int k = 0; k < rt_context::kPipes; ++k) {
@@ -1023,6 +1047,8 @@ static int upload_scene_one(rt_context *c, const rt_scene_desc *d) {
     // host-side table; rt_render_noalloc_dev allocates nothing, on the host side either)
     (void)resident_grid(c, RT_PICK(k_extend_stream, c, false), stream_lds_bytes_of(c));
     (void)resident_grid(c, RT_PICK(k_shadow_stream, c, false), stream_lds_bytes_of(c));
+    (void)resident_grid(c, RT_PICK(k_extend_refill, c, false), trace_lds_bytes(c));
+    (void)resident_grid(c, RT_PICK(k_extend_refill, c, true), trace_lds_bytes(c));
     return RT_OK;
 }
 
@@ -1244,7 +1270,8 @@ int rt_develop(rt_context *c, const float *rgb, const float *wsum, float film_sc
 static int set_option_one(rt_context *c, int option, int value) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (option == RT_OPTION_TRACE_SCHEDULE) {
-        if (value != RT_SCHEDULE_AUTO && value != RT_SCHEDULE_LOCKSTEP && value != RT_SCHEDULE_STREAM) return fail(c, RT_ERR_INVALID_ARG, "unknown trace schedule");
+        if (value != RT_SCHEDULE_AUTO && value != RT_SCHEDULE_LOCKSTEP && value != RT_SCHEDULE_STREAM && value != RT_SCHEDULE_REFILL)
+            return fail(c, RT_ERR_INVALID_ARG, "unknown trace schedule");
         c->traceSchedule = value;
         return RT_OK;
     }

@@ -220,7 +220,7 @@ class Context:
 
     def set_trace_schedule(self, schedule):
         """Ray-to-lane schedule: "auto" (default), "lockstep" (one ray per lane) or "stream" (lanes take new rays as they finish)."""
-        value = {"auto": 0, "lockstep": 1, "stream": 2}[schedule]
+        value = {"auto": 0, "lockstep": 1, "stream": 2, "refill": 3}[schedule]
         self._check(self._lib.rt_set_option(self._h, 1, value))
 
     def set_pipelines(self, n):

@@ -6,7 +6,7 @@
 // the 16 bytes of padding the library's upload adds), every wave-wide operation is reached by all live lanes together, and
 // every wave ends.
 //
-//   emu_trace <scene.bin> <rays.bin> <out.bin> <lockstep|stream>[-lds] <blocks> <any-hit tMax>
+//   emu_trace <scene.bin> <rays.bin> <out.bin> <lockstep|stream|refill>[-lds] <blocks> <any-hit tMax>
 //
 // The -lds suffix selects the flavour for scenes whose tables fit in LDS: three copies of the triangle table, one per axis
 // permutation of the triangle test, and the short LDS part of the todo stack.
@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../raytracing_amd/csrc/device/dstream.h"
+#include "../../raytracing_amd/csrc/device/drefill.h"
 
 namespace {
 
@@ -53,7 +54,7 @@ struct Batch {
 
 // One launch of `blocks` workgroups, wave after wave. LDS_SCENE picks the template flavour exactly as the kernels do.
 template <bool LDS_SCENE>
-bool run_grid(const DevScene &sc, const SceneTables &tb, const Batch &b, bool stream, bool closest, unsigned blocks, unsigned long long maxOps) {
+bool run_grid(const DevScene &sc, const SceneTables &tb, const Batch &b, bool stream, bool refill, bool closest, unsigned blocks, unsigned long long maxOps) {
     constexpr int SL = StackCfg<LDS_SCENE>::LDS_N;
     // the workgroup's LDS: todo stack part and prepared-ray pool, exact sizes
     std::vector<uint32_t> ldsStack((size_t)SL * 2 * RT_BLOCK);
@@ -62,7 +63,18 @@ bool run_grid(const DevScene &sc, const SceneTables &tb, const Batch &b, bool st
         simt::launch.blockIdx_ = simt::Dim3{blk, 0, 0};
         for (unsigned w = 0; w < RT_BLOCK / 64; ++w) {
             bool ok;
-            if (stream) {
+            if (refill) {
+                ok = simt::run_wave(w, [&]() {
+                    TravCounters cn = {0, 0, 0, 0, 0};
+                    if (closest) {
+                        TraceClosestJob job = {b.o, b.d, nullptr, b.prim, b.t, b.bary};
+                        trace_refill<true, false, SL, LDS_SCENE, false>(sc, tb, ldsStack.data(), (uint32_t)b.n, job, cn);
+                    } else {
+                        TraceAnyJob job = {b.o, b.d, b.tmaxAny, b.occ};
+                        trace_refill<false, false, SL, LDS_SCENE, false>(sc, tb, ldsStack.data(), (uint32_t)b.n, job, cn);
+                    }
+                }, maxOps);
+            } else if (stream) {
                 ok = simt::run_wave(w, [&]() {
                     TravCounters cn = {0, 0, 0, 0, 0};
                     if (closest) {
@@ -128,6 +140,7 @@ int main(int argc, char **argv) {
     fclose(f);
     const std::string mode = argv[4];
     const bool stream = mode.rfind("stream", 0) == 0;
+    const bool refill = mode.rfind("refill", 0) == 0;
     const bool ldsScene = mode.size() > 4 && mode.compare(mode.size() - 4, 4, "-lds") == 0;
     const unsigned blocks = (unsigned)atoi(argv[5]);
     const float anyTMax = (float)atof(argv[6]);
@@ -166,8 +179,8 @@ int main(int argc, char **argv) {
     const unsigned long long maxOps = 64ull * 1000 * 1000;
     const Batch batch = {n, o.data(), d.data(), anyTMax, prim.data(), t.data(), bary.data(), tmaxAny.data(), occ.data()};
     for (int closest = 1; closest >= 0; --closest) {
-        const bool ok = ldsScene ? run_grid<true>(sc, tb, batch, stream, closest != 0, blocks, maxOps)
-                                 : run_grid<false>(sc, tb, batch, stream, closest != 0, blocks, maxOps);
+        const bool ok = ldsScene ? run_grid<true>(sc, tb, batch, stream, refill, closest != 0, blocks, maxOps)
+                                 : run_grid<false>(sc, tb, batch, stream, refill, closest != 0, blocks, maxOps);
         if (!ok) return 3;
     }
     for (uint64_t i = 0; i < n; ++i)

@@ -28,7 +28,7 @@ def _build(merged, t_min=1):
     """g++ on tests/emu/emu_trace.cpp (a few seconds); rebuilt when a source it includes is newer."""
     exe = os.path.join(BIN, f"emu_trace_m{merged}" + (f"t{t_min}" if t_min > 1 else ""))
     sources = [os.path.join(ROOT, "tests", "emu", n) for n in ("emu_trace.cpp", "simt.h", os.path.join("hip", "hip_runtime.h"))]
-    sources += [os.path.join(ROOT, "raytracing_amd", "csrc", "device", n) for n in ("dstream.h", "dtraverse.h", "dmath.h")]
+    sources += [os.path.join(ROOT, "raytracing_amd", "csrc", "device", n) for n in ("dstream.h", "drefill.h", "dtraverse.h", "dmath.h")]
     if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(s) for s in sources):
         return exe
     if shutil.which("g++") is None:
@@ -89,7 +89,7 @@ def _run(exe, tmp, n, mode, blocks):
     return (raw[:4 * n].view(np.int32), raw[4 * n:8 * n].view(np.float32), raw[8 * n:20 * n].view(np.float32).reshape(n, 3), raw[20 * n:], r.stdout)
 
 
-@pytest.mark.parametrize("merged,t_min,mode,blocks", [(0, 1, "lockstep", 2), (0, 1, "stream", 1), (0, 1, "stream", 3), (1, 1, "stream", 1),
+@pytest.mark.parametrize("merged,t_min,mode,blocks", [(0, 1, "lockstep", 2), (0, 1, "stream", 1), (0, 1, "stream", 3), (0, 1, "refill", 1), (0, 1, "refill", 3), (1, 1, "stream", 1),
                                                       (1, 1, "stream", 3), (1, 12, "stream", 2)])
 def test_device_tracers_on_the_cpu_match_the_oracle(batch, merged, t_min, mode, blocks):
     tmp, n, prim, t, bary, occ = batch
@@ -101,7 +101,7 @@ def test_device_tracers_on_the_cpu_match_the_oracle(batch, merged, t_min, mode, 
     assert np.array_equal(ga, occ)
 
 
-@pytest.mark.parametrize("mode,blocks", [("lockstep-lds", 2), ("stream-lds", 1), ("stream-lds", 3)])
+@pytest.mark.parametrize("mode,blocks", [("lockstep-lds", 2), ("stream-lds", 1), ("stream-lds", 3), ("refill-lds", 1), ("refill-lds", 3)])
 def test_device_tracers_for_scenes_in_lds_on_the_cpu_match_the_oracle(batch_lds, mode, blocks):
     tmp, n, prim, t, bary, occ = batch_lds
     gp, gt, gb, ga, _ = _run(_build(0), tmp, n, mode, blocks)

@@ -24,7 +24,7 @@ def _closest_both_schedules(ctx, orc, o, d, label, tmax=None):
     """ids / t / barycentrics bit-equal to the oracle under both ray-to-lane schedules; returns the oracle's ids."""
     cp, ct, cb = orc.trace_closest(o, d, tmax)
     try:
-        for schedule in ("lockstep", "stream"):
+        for schedule in ("lockstep", "stream", "refill"):
             ctx.set_trace_schedule(schedule)
             gp, gt, gb = ctx.trace_closest(o, d, tmax)
             assert np.array_equal(gp, cp), f"{label}/{schedule}: {np.count_nonzero(gp != cp)} of {len(gp)} primitive ids differ"
@@ -38,7 +38,7 @@ def _closest_both_schedules(ctx, orc, o, d, label, tmax=None):
 def _any_both_schedules(ctx, orc, o, d, tmax, label):
     c = orc.trace_any(o, d, tmax)
     try:
-        for schedule in ("lockstep", "stream"):
+        for schedule in ("lockstep", "stream", "refill"):
             ctx.set_trace_schedule(schedule)
             assert np.array_equal(ctx.trace_any(o, d, tmax), c), f"{label}/{schedule}"
     finally:

@@ -10,7 +10,7 @@ from oracle_lib import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["lockstep", "stream"])
+@pytest.fixture(autouse=True, params=["lockstep", "stream", "refill"])
 def trace_schedule(request, gpu_ctx):
     """Every test of this module runs under both ray-to-lane schedules of the batch tracers."""
     gpu_ctx.set_trace_schedule(request.param)

@@ -33,6 +33,7 @@ def main():
     occ = torch.empty(n, dtype=torch.uint8, device=dev)
 
     def timed(fn):
+        torch.cuda.synchronize()   # the batch was made by torch kernels on torch's stream; the library launches on its own
         fn()
         ctx.synchronize()
         t0 = time.perf_counter()
@@ -43,9 +44,12 @@ def main():
 
     all_schedules = tuple(os.environ.get("RT_TB_SCHEDULES", "lockstep,stream").split(","))
     quick = os.environ.get("RT_TB_QUICK") == "1"   # only the ungrouped batches
+    only = [w for w in os.environ.get("RT_TB_ONLY", "").split(",") if w]   # e.g. "cosine,cosine2": only these batches are timed
 
     def run(name, o, d, schedules=None):
         if quick and ("/" in name):
+            return
+        if only and name not in only:
             return
         o = o.contiguous()
         d = d.contiguous()
@@ -122,6 +126,7 @@ def main():
     # the same rays grouped by the primitive they start on, and by primitive and direction octant (global stable sorts:
     # an upper bound on what binning the queue appends could give)
     ctx.set_trace_schedule("lockstep")
+    torch.cuda.synchronize()
     ctx.trace_closest_dev(n, ocam.contiguous().data_ptr(), dcam.contiguous().data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr())
     ctx.synchronize()
     start_prim = prim[hitmask][reps_idx].clone()
@@ -136,6 +141,7 @@ def main():
     # third bounce: from the hit points of those, again cosine-distributed
     ctx.set_trace_schedule("lockstep")
     o2, d2 = ph[reps_idx].contiguous(), dcos[reps_idx].contiguous()
+    torch.cuda.synchronize()
     ctx.trace_closest_dev(n, o2.data_ptr(), d2.data_ptr(), 0, prim.data_ptr(), t.data_ptr(), bary.data_ptr())
     ctx.synchronize()
     h2 = prim >= 0
