@@ -10,6 +10,15 @@
 #define RT_DYNAMIC_LDS(name) extern __shared__ uint4 name[]
 #endif
 
+// Wave-wide vote on a bool (the compare's own lane mask: no conversion of the predicate to an integer and back), and a
+// 24-bit multiply (full rate; a 32-bit one takes four issue slots).
+#ifndef RT_BALLOT
+#define RT_BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
+#endif
+#ifndef RT_MUL24
+#define RT_MUL24(a, b) __umul24((a), (b))
+#endif
+
 #define RT_DEV __device__ __forceinline__
 #define RT_HD __host__ __device__ __forceinline__
 

@@ -46,17 +46,21 @@ RT_DEV void trace_refill(const DevScene &sc, const SceneTables &tb, uint32_t *ld
     r.kz = 2;
     r.Sx = r.Sy = r.Sz = 0.f;
     float rayTMax = 0.f, tMin = 0.f, tMax = 0.f;
-    uint32_t node = 0, jobId = 0, leafBase = 0, triBase = 0;
-    int sp = 0, leafI = 0, leafN = 0;
+    uint32_t node = 0, jobId = 0, triBase = 0;
+    int sp = 0;
+    // Where the lane stands: left > 0 primitives of the current leaf still to test, left == 0 between leaves, left < 0 no ray.
+    // leafPos is the position of the leaf's next primitive in the index list; a leaf of one primitive names the primitive
+    // itself, marked by the top bit.
+    int left = -1;
+    uint32_t leafPos = 0;
     // closest hit so far; its distance is rayTMax (a ray that found nothing still carries the tMax it came with)
     int hitPrim = -1;
     float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
-    bool active = false;
 
     auto finish = [&]() {
         const HitRec h = {hitPrim, rayTMax, hb0, hb1, hb2};
         job.finish(jobId, h);
-        active = false;
+        left = -1;
     };
     // next todo entry; false when the ray is finished (stack empty, or the closest hit so far lies before the entry)
     auto pop = [&]() -> bool {
@@ -77,13 +81,13 @@ RT_DEV void trace_refill(const DevScene &sc, const SceneTables &tb, uint32_t *ld
     };
 
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = RT_BALLOT(left < 0);
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (cursor < total) {
             if (nIdle >= RT_RF_REFILL_MIN) {
                 const uint32_t rank = (uint32_t)__popcll(idle & below);
                 const uint32_t v = cursor + rank;
-                if (!active && v < total) {
+                if (left < 0 && v < total) {
                     const uint32_t j = (w0 + (v >> 6) * nWaves) * 64u + (v & 63u);
                     f3 o, d;
                     float ntm = 0.f;
@@ -96,10 +100,9 @@ RT_DEV void trace_refill(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                         hb0 = hb1 = hb2 = 0.f;
                         node = 0;
                         sp = 0;
-                        leafI = leafN = 0;
                         triBase = tri_table_base<PERM>(sc, r.kz);
-                        active = bounds_clip(sc, r, ntm, tMin, tMax);
-                        if (!active || (CLOSEST && rayTMax < tMin)) finish();
+                        left = 0;
+                        if (!bounds_clip(sc, r, ntm, tMin, tMax) || (CLOSEST && rayTMax < tMin)) finish();
                     }
                 }
                 cursor += nIdle < total - cursor ? nIdle : total - cursor;
@@ -110,7 +113,7 @@ RT_DEV void trace_refill(const DevScene &sc, const SceneTables &tb, uint32_t *ld
 
         // descend: one node per lane and round; more rounds while enough of the wave is still between leaves
         for (;;) {
-            if (active && leafI >= leafN) {
+            if (left == 0) {
                 const uint2 nd = tb.nodes[node];
                 if ((nd.y & 3u) != 3u) {
                     if (STATS) ++cn.interior;
@@ -143,32 +146,32 @@ RT_DEV void trace_refill(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                     if (STATS) ++cn.leaf;
                     const int nP = (int)(nd.y >> 2);
                     if (nP > 0) {
-                        leafN = nP;
-                        leafI = 0;
-                        leafBase = nd.x;
+                        left = nP;
+                        leafPos = nP == 1 ? (nd.x | 0x80000000u) : nd.x;
                     } else if (!pop()) {   // empty leaf
                         finish();
                     }
                 }
             }
-            if ((uint32_t)__popcll(__ballot(active && leafI >= leafN)) < RT_RF_D_MAJ) break;
+            if ((uint32_t)__popcll(RT_BALLOT(left == 0)) < RT_RF_D_MAJ) break;
         }
         // test: one primitive per lane and round; more rounds while enough of the wave is inside leaves
         for (;;) {
-            if (active && leafI < leafN) {
+            if (left > 0) {
                 int prim;
-                if (leafN == 1) prim = (int)leafBase;
+                if ((int)leafPos < 0) prim = (int)(leafPos & 0x7fffffffu);
                 else {
-                    prim = tb.leafIdx[leafBase + (uint32_t)leafI];
+                    prim = tb.leafIdx[leafPos];
                     if (STATS) ++cn.leafIdx;
                 }
+                ++leafPos;
+                --left;
                 if (STATS) ++cn.tri;
-                const uint32_t rec = tri_record(triBase, prim);
+                const uint32_t rec = tri_record<PERM>(triBase, prim);
                 const float4 q0 = tb.triHot[rec + 0];
                 const float4 q1 = tb.triHot[rec + 1];
                 const float4 q2 = tb.triHot[rec + 2];
                 float t, b0, b1, b2;
-                ++leafI;
                 bool accepted;
                 if (SPH && q0.w == RT_PRIM_SPHERE) {
                     f3 oo, dd;
@@ -188,12 +191,9 @@ RT_DEV void trace_refill(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                         hb0 = b0; hb1 = b1; hb2 = b2;
                     }
                 }
-                if (active && leafI == leafN) {
-                    leafI = leafN = 0;
-                    if (!pop()) finish();
-                }
+                if (left == 0 && !pop()) finish();
             }
-            if ((uint32_t)__popcll(__ballot(active && leafI < leafN)) < RT_RF_T_MAJ) break;
+            if ((uint32_t)__popcll(RT_BALLOT(left > 0)) < RT_RF_T_MAJ) break;
         }
     }
 }

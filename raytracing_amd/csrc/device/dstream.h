@@ -335,7 +335,7 @@ RT_DEV void trace_stream(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                     if (STATS) ++cn.leafIdx;
                 }
                 if (STATS) ++cn.tri;
-                const uint32_t rec = tri_record(triBase, prim);
+                const uint32_t rec = tri_record<PERM>(triBase, prim);
                 const float4 q0 = tb.triHot[rec + 0];
                 const float4 q1 = tb.triHot[rec + 1];
                 const float4 q2 = tb.triHot[rec + 2];

@@ -249,9 +249,11 @@ template <bool PERM> RT_DEV uint32_t tri_table_base(const DevScene &sc, int kz) 
     return PERM ? (uint32_t)(kz == 2 ? 0 : kz + 1) * sc.nPrims * 3u : 0u;
 }
 
-// Index of a primitive's first float4 in the triangle table: 32-bit shifts and adds (3 * prim as a multiply would be a
-// quarter-rate instruction, and 64-bit pointer arithmetic on a per-lane index costs as much).
-RT_DEV uint32_t tri_record(uint32_t triBase, int prim) { return triBase + (((uint32_t)prim << 1) + (uint32_t)prim); }
+// Index of a primitive's first float4 in the triangle table. Tables in LDS (PERM; a few hundred primitives at most): one
+// 24-bit multiply-add; written as 3 * prim the compiler forms a 64-bit multiply-add per lane, four issue slots.
+template <bool PERM> RT_DEV uint32_t tri_record(uint32_t triBase, int prim) {
+    return PERM ? RT_MUL24((uint32_t)prim, 3u) + triBase : 3u * (uint32_t)prim + triBase;
+}
 
 // SPH: the scene has sphere primitives (scenes without them compile the sphere test away).
 template <bool CLOSEST, bool STATS, int SL, bool PERM, bool SPH>
@@ -315,7 +317,7 @@ RT_DEV bool kd_trace(const DevScene &sc, const SceneTables &tb, uint32_t *ldsSta
                 if (STATS) ++cn.leafIdx;
             }
             if (STATS) ++cn.tri;
-            const uint32_t rec = tri_record(triBase, prim);
+            const uint32_t rec = tri_record<PERM>(triBase, prim);
             const float4 q0 = tb.triHot[rec + 0];
             const float4 q1 = tb.triHot[rec + 1];
             const float4 q2 = tb.triHot[rec + 2];

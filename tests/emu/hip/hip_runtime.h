@@ -64,6 +64,8 @@ template <typename T> static inline T atomicMin(T *p, T v) { const T old = *p; i
 
 // wave-wide operations and barriers: every live lane that takes part must reach the same one (checked by source line)
 #define __ballot(pred) simt::ballot((pred), __LINE__)
+#define RT_BALLOT(pred) simt::ballot((pred), __LINE__)
+#define RT_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))
 #define __builtin_amdgcn_wave_barrier() simt::wave_barrier(__LINE__)
 #define __syncthreads() simt::block_barrier(__LINE__)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
