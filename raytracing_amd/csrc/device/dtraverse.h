@@ -70,7 +70,7 @@ struct DevScene {
     const float *lightFunc;   // nLights
     const DevSphere *spheres;
     float bmin[3], bmax[3];
-    uint32_t nNodes, nLeafIdx, nPrims, nMats, nLights;
+    uint32_t nNodes, nLeafIdx, nPrims, nMats, nLights, nSpheres;
     float lightFuncInt;
     uint32_t ldsSceneBytes;   // nodes + leafIdx + triHot, each padded to 16 B; 0 = does not fit in LDS
     uint32_t triCopies;       // 3 when triHot holds the permuted copies, else 1

@@ -367,11 +367,49 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RF_MIN_BLOCKS) void k_extend_refill(De
 #ifndef RT_SHADE_MIN_BLOCKS
 #define RT_SHADE_MIN_BLOCKS 2   // workgroups per CU the register allocation of k_shade is held to
 #endif
-template <int MATSET, bool SPH>
-__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScene sc, CameraDev cam, PassInfo ps, PathBuffers pb, int bounce) {
+// The tables shading reads (primitive records, shading records, materials, lights, light selection tables, spheres) as one
+// block of 16-byte vectors in LDS, for scenes where that is a few kilobytes: a shaded hit follows a chain of dependent reads
+// through them (primitive -> material, light choice -> light -> its primitive), which costs a memory round trip per link
+// from HBM or L2 and a few dozen cycles from LDS.
+RT_HD uint32_t shade_tables_vecs(uint32_t nPrims, uint32_t nMats, uint32_t nLights, uint32_t nSpheres) {
+    return nPrims * 3u + nPrims * 5u + nMats * 2u + nLights * 2u + (nLights + 1u + 3u) / 4u + (nLights + 3u) / 4u + nSpheres * 9u;
+}
+RT_DEV void stage_shade_tables(DevScene &sc, uint4 *smem) {
+    const uint32_t counts[7] = {sc.nPrims * 3u, sc.nPrims * 5u, sc.nMats * 2u, sc.nLights * 2u, (sc.nLights + 1u + 3u) / 4u,
+                                (sc.nLights + 3u) / 4u, sc.nSpheres * 9u};
+    const uint4 *src[7] = {reinterpret_cast<const uint4 *>(sc.triHot),   reinterpret_cast<const uint4 *>(sc.triShade),
+                           reinterpret_cast<const uint4 *>(sc.mats),     reinterpret_cast<const uint4 *>(sc.lights),
+                           reinterpret_cast<const uint4 *>(sc.lightCdf), reinterpret_cast<const uint4 *>(sc.lightFunc),
+                           reinterpret_cast<const uint4 *>(sc.spheres)};
+    uint32_t at[8];
+    at[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        for (uint32_t i = threadIdx.x; i < counts[k]; i += blockDim.x) smem[at[k] + i] = src[k][i];
+        at[k + 1] = at[k] + counts[k];
+    }
+    sc.triHot = reinterpret_cast<const float4 *>(smem + at[0]);
+    sc.triShade = reinterpret_cast<const float4 *>(smem + at[1]);
+    sc.mats = reinterpret_cast<const DevMaterial *>(smem + at[2]);
+    sc.lights = reinterpret_cast<const DevLight *>(smem + at[3]);
+    sc.lightCdf = reinterpret_cast<const float *>(smem + at[4]);
+    sc.lightFunc = reinterpret_cast<const float *>(smem + at[5]);
+    sc.spheres = reinterpret_cast<const DevSphere *>(smem + at[6]);
+    __syncthreads();
+}
+
+// LDS_TABLES: the launch gives 16 * shade_tables_vecs(...) bytes of dynamic LDS and the kernel shades out of a copy there.
+template <int MATSET, bool SPH, bool LDS_TABLES>
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScene scene, CameraDev cam, PassInfo ps, PathBuffers pb, int bounce) {
     const int cur = bounce & 1, nxt = cur ^ 1;
     __shared__ uint32_t s_app[16];
     const uint32_t n = pb.counts[cnt_index(bounce, 0)];
+    if (blockIdx.x * RT_BLOCK >= n) return;   // no chunk for this workgroup
+    DevScene sc = scene;
+    if (LDS_TABLES) {
+        RT_DYNAMIC_LDS(smem);
+        stage_shade_tables(sc, smem);
+    }
     uint32_t *cntNext = &pb.counts[cnt_index(bounce + 1, 0)];
     uint32_t *cntShadow = &pb.counts[cnt_index(bounce, 1)];
     uint32_t *cntProbe = &pb.counts[cnt_index(bounce, 2)];

@@ -100,6 +100,7 @@ struct rt_context {
     // stats
     unsigned long long *dStats = nullptr;
     int traceSchedule = RT_SCHEDULE_AUTO;
+    size_t shadeLdsBytes = 0;   // dynamic LDS of k_shade when it shades out of a copy of the tables in LDS; 0 = tables in memory
     // first bounce whose extend / shadow stage runs the refilling kernels (scenes in LDS); experiments set them from the environment
     int refillExtendFrom = 1, refillShadowFrom = 1 << 30;
     int pipelines = RT_PIPES;   // RT_OPTION_PIPELINES
@@ -495,11 +496,13 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
                                    (const uint32_t *)&pb.counts[cnt_index(b, 0)], rs.stats, camOrigin);
             }
             if (ep) HIPCHK(c, hipEventRecord(ep->b, st));
-            auto ksh = c->hasSpheres ? (c->allLambert ? k_shade<MATSET_LAMBERT, true> : k_shade<MATSET_ANY, true>)
-                                     : (c->allLambert ? k_shade<MATSET_LAMBERT, false> : k_shade<MATSET_ANY, false>);
+            auto ksh = c->shadeLdsBytes ? (c->hasSpheres ? (c->allLambert ? k_shade<MATSET_LAMBERT, true, true> : k_shade<MATSET_ANY, true, true>)
+                                                         : (c->allLambert ? k_shade<MATSET_LAMBERT, false, true> : k_shade<MATSET_ANY, false, true>))
+                                        : (c->hasSpheres ? (c->allLambert ? k_shade<MATSET_LAMBERT, true, false> : k_shade<MATSET_ANY, true, false>)
+                                                         : (c->allLambert ? k_shade<MATSET_LAMBERT, false, false> : k_shade<MATSET_ANY, false, false>));
             EventPair *es = rs.timeExtend ? next_event_pair(c->shadeEvents, c->shadeEventsUsed) : nullptr;
             if (es) HIPCHK(c, hipEventRecord(es->a, st));
-            hipLaunchKernelGGL(ksh, dim3(grid), dim3(RT_BLOCK), 0, st, c->sc, cam, ps, pb, b);
+            hipLaunchKernelGGL(ksh, dim3(grid), dim3(RT_BLOCK), c->shadeLdsBytes, st, c->sc, cam, ps, pb, b);
             if (es) HIPCHK(c, hipEventRecord(es->b, st));
             if (b < p->max_depth) {
                 if (streamTrace) {
@@ -1032,6 +1035,13 @@ static int upload_scene_one(rt_context *c, const rt_scene_desc *d) {
     sc.lightFunc = (const float *)c->dLightFunc;
     sc.spheres = (const DevSphere *)c->dSpheres;
     c->hasSpheres = d->n_spheres > 0;
+    sc.nSpheres = d->n_spheres;
+    // shading tables in LDS when they are small (cornellBox: 5 KB); beyond 16 KB the shade kernel reads them from memory
+    {
+        const size_t bytes = 16 * (size_t)shade_tables_vecs(d->n_prims, d->n_materials, d->n_lights, d->n_spheres);
+        c->shadeLdsBytes = (d->n_prims < (1u << 16) && bytes <= 16384) ? bytes : 0;
+        if (const char *v = std::getenv("RT_EXP_SHADE_LDS")) if (v[0] == '0') c->shadeLdsBytes = 0;
+    }
     for (int k = 0; k < 3; ++k) { sc.bmin[k] = d->bounds[k]; sc.bmax[k] = d->bounds[3 + k]; }
     sc.nNodes = d->n_nodes;
     sc.nLeafIdx = d->n_leaf_idx;
