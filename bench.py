@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X: cornellBox PathTracing at 1920x1080 (BASELINE configs[2]).
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W                        one process; N > 1: one context over N GPUs
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W     one process per GPU
 
-One step = one wavefront pass of SPP_PER_STEP samples per pixel over the whole 1080p frame on every rank
-(raygen, then extend/shade/shadow/probe for each bounce up to depth 15, then the film accumulation). Rank g
+One step = one wavefront pass of SPP_PER_STEP samples per pixel over the whole 1080p frame on every GPU
+(raygen, then extend/shade/shadow/probe for each bounce up to depth 15, then the film accumulation). GPU g
 renders sample indices [g*K*P, (g+1)*K*P) of a (N*K*P)-spp job; after the K steps the float film (one packed buffer of
-4 W H floats) is sum-reduced to rank 0 over RCCL inside the timed region. The scene is resident in HBM and camera rays
+4 W H floats) is sum-reduced to GPU 0 over RCCL inside the timed region. The scene is resident in HBM and camera rays
 are generated on the device, so no host data moves in the timed region.
+
+Two hosts for N > 1 (the same split, the same single reduce):
+  group   plain `python bench.py --gpus N` (no WORLD_SIZE in the environment): ONE process, as the reference's main is one
+          process that calls render() once (reference src/RayTracing.cpp:32-33); the library's multi-GPU context
+          (rt_create_multi) shards the job and runs its own ncclReduce. On a machine with fewer than N GPUs device 0 is
+          listed N times, which is the library's one-GPU rehearsal of that path ("rehearsal": true in the line).
+  ranks   under torch.distributed.run: one process and one rt_create context per GPU, reduce through torch.distributed.
 
 Prints ONE JSON line (rank 0). value = whole-job Mrays/s, one ray = one KD-tree traversal of either flavour
 (extend + MIS-probe + shadow), counted by the kernels themselves. Besides the contract's fields the line carries
@@ -50,6 +57,8 @@ PMC = {
     "extend_lds_conflict_cycles": 0.39,     # SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS
     "shade_hbm_bytes_per_path": 128.0,      # k_shade: (FETCH_SIZE x 2 + WRITE_SIZE) per ray entering the kernel
     "shade_lanes_active": 54.3,
+    "extend_valu_per_ray": 56.6,            # SQ_INSTS_VALU per ray of the refilling kernel on third-bounce rays (lockstep: 88.9)
+    "valu_source": "profiles/r03_refill_compact_trace_bench.txt",
 }
 PMC_SOUP = {
     "source": "profiles/r02_soup_tuned_pmc_incoherent.md",
@@ -173,6 +182,7 @@ def soup_secondary(torch, dev, base_cfg, with_cpu):
     }
     # path tracing on the same scene: 16 spp is one pass; 128 spp is four passes of 32 spp that overlap on three pipelines
     ctx.set_camera(cfg)
+    ctx.set_kernel_times(True)   # these two jobs report launch times; their seconds include the (small) cost of the events
     rgb = torch.zeros((cfg.height, cfg.width, 3), dtype=torch.float32, device=dev)
     w = torch.zeros((cfg.height, cfg.width), dtype=torch.float32, device=dev)
     for spp in (16, 128):
@@ -216,7 +226,46 @@ def soup_secondary(torch, dev, base_cfg, with_cpu):
     return out
 
 
-def main():
+def plan(gpus, environ):
+    """How this invocation runs: 'single' (one GPU), 'group' (one process, one context over `gpus` GPUs) or 'ranks' (one
+    process per GPU, started by torch.distributed.run). Never refuses: `--gpus N` without a launcher is the group form."""
+    world = int(environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        return {"mode": "ranks", "world": world, "rank": int(environ.get("RANK", "0")), "local_rank": int(environ.get("LOCAL_RANK", "0"))}
+    if gpus > 1:
+        return {"mode": "group", "world": gpus, "rank": 0, "local_rank": 0}
+    return {"mode": "single", "world": 1, "rank": 0, "local_rank": 0}
+
+
+def c1_job(torch, dev, scene):
+    """BASELINE configs[0] on the GPU: the reference's own CPU-runnable case (cornellBox PathTracing 800x800, 512 spp, depth
+    15), the one job for which a time of the reference itself exists (202.6 s on 8 vCPU, measured by the survey)."""
+    from raytracing_amd.device import Context
+    cfg = scene.config.with_resolution(800, 800, spp=512)
+    ctx = Context(dev.index)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cfg)
+    rgb = torch.zeros((800, 800, 3), dtype=torch.float32, device=dev)
+    w = torch.zeros((800, 800), dtype=torch.float32, device=dev)
+    kw = dict(integrator=0, rng_mode=0, seed=1, spp=512, max_depth=MAX_DEPTH)
+    ctx.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)   # warm-up: allocates the queues
+    ctx.synchronize()
+    rgb.zero_()
+    w.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    assert float(w.min()) >= 512
+    ctx.close()
+    return {"job": "cornellBox PathTracing 800x800 x 512 spp, depth 15 (BASELINE configs[0]), counter RNG, film in device memory",
+            "gpu_seconds": dt, "reference_cpu_seconds": 202.6, "reference_cpu_cores": 8,
+            "ratio": 202.6 / dt,
+            "note": "the reference itself, compiled and timed by the survey on 8 vCPU; the only like-for-like GPU / reference-CPU figure"}
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
@@ -224,7 +273,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1 M-triangle soup (BASELINE configs[3])")
     ap.add_argument("--no-strong", action="store_true", help="skip the 1024-spp strong-scaling job")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    pl = plan(args.gpus, os.environ)   # decided before anything touches a GPU
+    mode, world, rank, local_rank = pl["mode"], pl["world"], pl["rank"], pl["local_rank"]
 
     import torch
     import torch.distributed as dist
@@ -232,21 +283,16 @@ def main():
     from raytracing_amd.distributed import shard_range
     from raytracing_amd.scene import FlatScene
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the device path has no CPU fallback")
-    local_dev = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in a rehearsal with fewer GPUs than ranks
+    n_visible = torch.cuda.device_count()
+    local_dev = local_rank % n_visible   # one rank per GPU; wraps only in a rehearsal with fewer GPUs than ranks
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    # RCCL is the transport; "gloo" (RT_BENCH_BACKEND) only rehearses the multi-rank logic on a box with fewer GPUs than
+    # ranks: RCCL is the transport; "gloo" (RT_BENCH_BACKEND) only rehearses the multi-rank logic on a box with fewer GPUs than
     # ranks, where RCCL refuses two ranks on one device - it stages the film through host memory and is not a measurement
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
-    if world > 1:
+    if mode == "ranks":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -264,7 +310,13 @@ def main():
 
     scene = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornellBox_path.npz"))
     cfg = scene.config.with_resolution(WIDTH, HEIGHT, spp=SPP_PER_STEP)
-    ctx = Context(local_dev)
+    rehearsal = False
+    if mode == "group":
+        # one context over `world` GPUs; with fewer GPUs than that, the library's one-GPU rehearsal of the same code path
+        rehearsal = n_visible < world
+        ctx = Context(device_ids=[0] * world if rehearsal else list(range(world)))
+    else:
+        ctx = Context(local_dev)
     ctx.upload_scene(scene)
     ctx.set_camera(cfg)
 
@@ -280,10 +332,20 @@ def main():
         ctx.render_dev(rgb.data_ptr(), wsum.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=total, max_depth=MAX_DEPTH,
                        spp_begin=spp_begin, spp_end=spp_end, spp_per_pass=P, collect_stats=collect)
 
+    def job(begin_of_rank0, per_gpu, total):
+        """`per_gpu` samples per pixel on every GPU of a `total`-spp job, film summed on GPU 0: in ranks mode this rank's
+        shard and the reduce; in group mode ONE call, the library shards it and runs its own reduce."""
+        if mode == "ranks":
+            run(begin_of_rank0 + rank * per_gpu, begin_of_rank0 + (rank + 1) * per_gpu, total)
+            ctx.synchronize()   # the render runs on the library's own streams; RCCL runs on torch's
+            reduce_to_rank0(film)
+        else:
+            run(begin_of_rank0, begin_of_rank0 + world * per_gpu, total)
+
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if mode == "ranks":
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -294,67 +356,73 @@ def main():
     st = ctx.stats()
     cr = max(1, st["counted_rays"])
     ni, nl, nidx, ntri = st["n_interior"] / cr, st["n_leaf"] / cr, st["n_leaf_idx"] / cr, st["n_tri_tests"] / cr
-    # warmup steps (untimed)
-    if W > 0:
-        run(0, W * P, W * P)
-    if world > 1:
-        # first use of the collectives (communicator set-up, channel buffers) belongs to the warm-up, not to the timed steps
-        ctx.synchronize()
-        reduce_to_rank0(film)
+    # warmup steps (untimed); with more than one GPU they include the first use of the collective (communicator set-up,
+    # channel buffers)
+    if W > 0 or world > 1:
+        job(0, max(1, W) * P, world * max(1, W) * P)
     fence()
     film.zero_()
     ctx.reset_stats()
     fence()
 
+    # timed region: no HIP events in the render's streams (RT_OPTION_KERNEL_TIMES is off)
     t0 = time.perf_counter()
-    run(rank * K * P, (rank + 1) * K * P, spp_total)
-    if world > 1:
-        ctx.synchronize()   # the render runs on the library's own streams; RCCL runs on torch's
-        reduce_to_rank0(film)
+    job(0, K * P, spp_total)
     fence()
     elapsed = time.perf_counter() - t0
 
     st = ctx.stats()
     wmin = float(wsum.min()) if rank == 0 else 0.0
 
-    # BASELINE configs[2] as worded: one 1024-spp job, spp-sharded over the ranks, reduce included (strong scaling)
+    # BASELINE configs[2] as worded: one 1024-spp job, spp-sharded over the GPUs, reduce included (strong scaling)
     strong = None
     if not args.no_strong and world <= STRONG_SPP:
-        sb, se = shard_range(STRONG_SPP, rank, world)
         film.zero_()
         ctx.reset_stats()
         fence()
         ts = time.perf_counter()
-        run(sb, se, STRONG_SPP)
-        if world > 1:
+        if mode == "ranks":
+            sb, se = shard_range(STRONG_SPP, rank, world)
+            run(sb, se, STRONG_SPP)
             ctx.synchronize()
             reduce_to_rank0(film)
+        else:
+            sb, se = shard_range(STRONG_SPP, 0, world)   # the library cuts the job by the same rule
+            run(0, STRONG_SPP, STRONG_SPP)
         fence()
         strong_elapsed = time.perf_counter() - ts
         sst = ctx.stats()
         strong = (strong_elapsed, float(sst["rays_closest"] + sst["rays_any"]), float(sst["camera_samples"]),
                   float(wsum.min()) if rank == 0 else 0.0, -(-(se - sb) // P))
 
-    # k_extend alone on the device: one more step with the passes run one after the other (untimed). In the timed region
-    # kernels of three passes share the CUs, which is faster overall but stretches every single launch.
-    exclusive = None
+    # Kernel launch times, outside the timed region: the same steps once more with HIP events around the extend and shade
+    # launches (three passes share the CUs, as in the timed region), then one step with the passes run one after the other
+    # ("exclusive": a kernel alone on the device).
+    timed_launches = exclusive = None
     if rank == 0:
+        members = world if mode == "group" else 1   # a group cuts the job by sample index: the same passes per GPU as above
+        ctx.set_kernel_times(True)
+        ctx.reset_stats()
+        run(0, min(K, 8) * P * members, min(K, 8) * P * members)
+        ctx.synchronize()
+        timed_launches = ctx.stats()
         ctx.set_pipelines(1)
         try:
             ctx.reset_stats()
-            run(0, P, P)
+            run(0, P * members, P * members)
             ctx.synchronize()
             sx = ctx.stats()
             if sx["extend_ms"] > 0:
                 exclusive = sx
         finally:
             ctx.set_pipelines(3)
+            ctx.set_kernel_times(False)
     vals = [elapsed, float(st["rays_closest"] + st["rays_any"]), float(st["camera_samples"])]
     vals += list(strong[:3]) if strong else [0.0, 0.0, 0.0]
     local = torch.tensor(vals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     tmax = local.clone()
     tsum = local.clone()
-    if world > 1:
+    if mode == "ranks":
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
     t = float(tmax[0])
@@ -363,14 +431,11 @@ def main():
     if rank == 0:
         # sanity: every pixel received exactly spp_total samples (plus rare border-rounded neighbours)
         assert wmin >= spp_total, f"film incomplete: min weight {wmin} < {spp_total}"
-        bpr = bytes_per_ray(ni, nl, nidx, ntri, closest=True)
-        fpr = flops_per_ray(ni, ntri, 1.0)
-        ext_rays, ext_ms, ext_launches = float(st["extend_rays"]), st["extend_ms"], max(1, st["extend_launches"])
-        sh_ms, sh_launches = st["shade_ms"], max(1, st["shade_launches"])
-        ext_s = max(ext_ms, 1e-9) * 1e-3
-        valu = fpr * ext_rays / ext_s / 1e12
-        hbm = PMC["extend_hbm_bytes_per_ray"] * ext_rays / ext_s / 1e9
-        shade_gbs = SHADE_BYTES_PER_PATH * ext_rays / (max(sh_ms, 1e-9) * 1e-3) / 1e9
+        if mode == "group":
+            how = ("rt_create_multi, one ncclReduce" if not rehearsal else
+                   "rt_create_multi on one GPU listed %d times (rehearsal: device-local sums stand in for the ncclReduce)" % world)
+        else:
+            how = f"one process per GPU, one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} sum-reduce through torch.distributed"
         out = {
             "metric": "Mrays/s (traversal+isect) and samples/sec, cornellBox 1080p, 1/2/4/8 GPUs",
             "value": rays / t / 1e6,
@@ -392,11 +457,27 @@ def main():
                 "spp_per_gpu": K * P,
                 "spp_total": spp_total,
                 "paths_in_flight_per_gpu": WIDTH * HEIGHT * P,
-                "parallelism": f"spp-sharded x{world}, one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} sum-reduce of the packed {WIDTH}x{HEIGHT}x4 float film",
+                "parallelism": f"spp-sharded x{world}: {how}; the film travels as one packed {WIDTH}x{HEIGHT}x4 float buffer",
+                "host": mode,
             },
             "rays_per_sample": rays / samples,
-            "roofline": {
-                "kernel": "k_extend (closest-hit KD traversal + triangle tests); the 8 KB of scene tables are staged in LDS",
+        }
+        if world > 1:
+            out["rccl_ranks"] = 0 if rehearsal else world
+            out["rehearsal"] = bool(rehearsal or (mode == "ranks" and backend != "nccl"))
+        if timed_launches is not None:
+            tl = timed_launches
+            bpr = bytes_per_ray(ni, nl, nidx, ntri, closest=True)
+            fpr = flops_per_ray(ni, ntri, 1.0)
+            ext_rays, ext_ms, ext_launches = float(tl["extend_rays"]), tl["extend_ms"], max(1, tl["extend_launches"])
+            sh_ms, sh_launches = tl["shade_ms"], max(1, tl["shade_launches"])
+            ext_s = max(ext_ms, 1e-9) * 1e-3
+            valu = fpr * ext_rays / ext_s / 1e12
+            hbm = PMC["extend_hbm_bytes_per_ray"] * ext_rays / ext_s / 1e9
+            shade_gbs = SHADE_BYTES_PER_PATH * ext_rays / (max(sh_ms, 1e-9) * 1e-3) / 1e9
+            out["roofline"] = {
+                "kernel": "k_extend / k_extend_refill (closest-hit KD traversal + triangle tests: lockstep for camera rays, refilling from the first "
+                          "bounce on); the 8 KB of scene tables are staged in LDS",
                 "bound": "valu",
                 "achieved": valu,
                 "peak": FP32_VALU_PEAK_TFLOPS,
@@ -408,24 +489,26 @@ def main():
                 "rays_per_launch": ext_rays / ext_launches,
                 "avg_launch_ms": ext_ms / ext_launches,
                 "launches": int(ext_launches),
+                "timing": "HIP events on the launching streams, in a repeat of the first steps outside the timed region (the timed region "
+                          "carries no events); three passes share the CUs as they do there",
                 "per_ray": {"interior": ni, "leaf": nl, "leaf_idx": nidx, "tri_tests": ntri},
                 "lanes_active_pmc": PMC["extend_lanes_active"],
-                "lds_bank_conflict_share_pmc": PMC["extend_lds_conflict_cycles"],
+                "vector_instructions_per_ray_pmc": PMC["extend_valu_per_ray"],
                 "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "bytes_per_ray_pmc": PMC["extend_hbm_bytes_per_ray"], "bytes_per_ray_unavoidable": 41.7},
                 "lds": {"bytes_per_ray_algorithmic": bpr - 44.0, "achieved_GBs": (bpr - 44.0) * ext_rays / ext_s / 1e9,
                         "note": "node, leaf-index and triangle bytes: served from LDS, not HBM traffic"},
                 "pmc_source": PMC["source"],
-                "note": "the vector ALUs issue every cycle with about 12 of 64 lanes active (a wave ends with its slowest ray): what binds "
-                        "is VALU issue under SIMD divergence, so frac is the useful-flop fraction of the FP32 vector peak",
-                "extend_share_of_step": ext_ms * 1e-3 / t,
-                "launch_overlap": "durations in the timed region include time shared with the kernels of two other passes "
-                                  "(three pipelines); 'exclusive' is the same kernel on the same queues with the passes "
-                                  "run one after the other, outside the timed region",
-            },
-            "roofline_shade": {
+                "note": "what binds is instruction issue under SIMD divergence (a wave issues every vector instruction for all 64 lanes "
+                        "whatever the number of live ones), so frac is the useful-flop fraction of the FP32 vector peak",
+                "launch_overlap": "durations include time shared with the kernels of two other passes (three pipelines); 'exclusive' is "
+                                  "the same kernels on the same queues with the passes run one after the other",
+            }
+            out["roofline_shade"] = {
                 "kernel": "k_shade (one bounce of PathRenderer::Li per ray: NEE + MIS, BSDF sample, Russian roulette, queue appends)",
-                "bound": "hbm",
+                "bound": "latency",
+                "bound_note": "neither roof binds: 70 % of wave-cycles are spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) at 3 waves per SIMD "
+                              "(134 registers), 54 of 64 lanes live; the HBM figures below say how far the kernel is from the byte roof",
                 "achieved": shade_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -436,34 +519,38 @@ def main():
                 "avg_launch_ms": sh_ms / sh_launches,
                 "launches": int(sh_launches),
                 "lanes_active_pmc": PMC["shade_lanes_active"],
-                "shade_share_of_step": sh_ms * 1e-3 / t,
-            },
-        }
-        if exclusive is not None:
-            xr, xms, xl = float(exclusive["extend_rays"]), exclusive["extend_ms"], max(1, exclusive["extend_launches"])
-            xv = fpr * xr / (xms * 1e-3) / 1e12
-            out["roofline"]["exclusive"] = {"achieved": xv, "unit": "TFLOP/s", "frac": xv / FP32_VALU_PEAK_TFLOPS, "avg_launch_ms": xms / xl,
-                                            "rays_per_launch": xr / xl,
-                                            "hbm_frac": PMC["extend_hbm_bytes_per_ray"] * xr / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            if exclusive["shade_ms"] > 0:
-                xs = SHADE_BYTES_PER_PATH * xr / (exclusive["shade_ms"] * 1e-3) / 1e9
-                out["roofline_shade"]["exclusive"] = {"achieved": xs, "unit": "GB/s", "frac": xs / HBM_PEAK_GBS,
-                                                      "avg_launch_ms": exclusive["shade_ms"] / max(1, exclusive["shade_launches"])}
+            }
+            if exclusive is not None:
+                xr, xms, xl = float(exclusive["extend_rays"]), exclusive["extend_ms"], max(1, exclusive["extend_launches"])
+                xv = fpr * xr / (xms * 1e-3) / 1e12
+                out["roofline"]["exclusive"] = {"achieved": xv, "unit": "TFLOP/s", "frac": xv / FP32_VALU_PEAK_TFLOPS, "avg_launch_ms": xms / xl,
+                                                "rays_per_launch": xr / xl,
+                                                "hbm_frac": PMC["extend_hbm_bytes_per_ray"] * xr / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if exclusive["shade_ms"] > 0:
+                    xs = SHADE_BYTES_PER_PATH * xr / (exclusive["shade_ms"] * 1e-3) / 1e9
+                    out["roofline_shade"]["exclusive"] = {"achieved": xs, "unit": "GB/s", "frac": xs / HBM_PEAK_GBS,
+                                                          "avg_launch_ms": exclusive["shade_ms"] / max(1, exclusive["shade_launches"])}
         if strong:
             ts_, srays, ssamples = float(tmax[3]), float(tsum[4]), float(tsum[5])
             assert strong[3] >= STRONG_SPP, f"strong-scaling film incomplete: min weight {strong[3]}"
             out["strong_1024spp"] = {"seconds": ts_, "samples_per_sec": ssamples / ts_, "Mrays_per_s": srays / ts_ / 1e6,
                                      "per_gpu_passes": strong[4], "spp_per_gpu": STRONG_SPP // world, "n_gpus": world,
-                                     "note": "one 1024-spp job split by sample index over the ranks, film reduce included; max over ranks"}
+                                     "note": "one 1024-spp job split by sample index over the GPUs, film reduce included; max over ranks"}
         if world == 1 and not args.no_secondary:
             out["secondary"] = soup_secondary(torch, dev, scene.config, with_cpu=not args.no_cpu_baseline)
+        if world == 1:
+            out["gpu_over_reference_cpu_c1"] = c1_job(torch, dev, scene)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cfg)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            out["gpu_over_reference_cpu"] = {"ratio": out["samples_per_sec"] / 1.617e6,
-                                             "reference": "1.617 M samples/s: the reference itself on 8 vCPU, cornellBox 800x800 x 512 spp (measured by the survey)"}
+            out["gpu_over_cpu"] = {"ratio": out["value"] / out["cpu_baseline"]["value"], "cores": out["cpu_baseline"]["cores"],
+                                   "host_cpu_count": os.cpu_count(), "baseline": "the CPU port (oracle) on this host, same frame"}
+            out["gpu_over_reference_cpu_cross_resolution"] = {
+                "ratio": out["samples_per_sec"] / 1.617e6, "cores": 8,
+                "note": "1080p samples per second here over the reference's 800x800 rate on 8 vCPU (1.617 M samples/s, measured by the "
+                        "survey): half of the 16:9 frame's camera rays miss the box (3.67 rays per sample against 5.75), so this is not a "
+                        "like-for-like ratio; gpu_over_reference_cpu_c1 is"}
         print(json.dumps(out))
-    if world > 1:
+    if mode == "ranks":
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

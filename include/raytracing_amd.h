@@ -134,7 +134,7 @@ typedef struct rt_stats {
     uint64_t n_leaf_idx;
     uint64_t n_tri_tests;
     uint64_t counted_rays;
-    /* HIP-event time of the closest-hit (extend) kernel launches since rt_reset_stats */
+    /* HIP-event time of the closest-hit (extend) kernel launches since rt_reset_stats (RT_OPTION_KERNEL_TIMES = 1) */
     uint64_t extend_launches;
     double extend_ms;
     uint64_t extend_rays;      /* rays processed by those launches */
@@ -164,13 +164,17 @@ int rt_create(int device_id, rt_context **out_ctx);
  * buffers (device pointers of the *_dev variants live on device_ids[0]). Jobs that cannot be cut by sample index (the
  * reference's tile stream) and the batch tracing, film development and no-allocation entry points run on device 0.
  * RCCL (librccl.so) is opened at run time and only when n_devices > 1; n_devices == 1 is rt_create. Listing one device
- * more than once is a one-GPU rehearsal of the same code path: RCCL refuses duplicate devices, so the films are then
- * summed by a device-local kernel in member order. rt_get_stats sums the counters over the devices. */
+ * n_devices times is a one-GPU rehearsal of the same code path: RCCL refuses duplicate devices, so the films are then
+ * summed by a device-local kernel in member order. Any other list with a repeated device is RT_ERR_INVALID_ARG.
+ * rt_get_stats sums the counters over the devices; its kernel times (extend_ms, shade_ms) are the slowest device's, since
+ * the devices run side by side, and render_ms is the host clock of the call. */
 int rt_create_multi(const int *device_ids, int n_devices, rt_context **out_ctx);
 int rt_device_count(const rt_context *ctx);   /* devices of the context (1 for rt_create) */
 /* The sample-index range member `member` of `n_members` renders of a job [spp_begin, spp_end): contiguous, balanced to
  * within one sample, the union over the members is the job. Host arithmetic only (no GPU needed); rt_render uses it, and
- * a caller that runs one process per GPU (one rt_create each) uses it to pick each process's spp_begin / spp_end. */
+ * a caller that runs one process per GPU (one rt_create each) uses it to pick each process's spp_begin / spp_end.
+ * n_members <= 0, a member outside [0, n_members) or spp_end < spp_begin give the empty range [spp_begin, spp_begin);
+ * a NULL output pointer is skipped. */
 void rt_shard_range(int spp_begin, int spp_end, int member, int n_members, int *out_begin, int *out_end);
 void rt_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);   /* ctx may be NULL: last creation error */
@@ -210,18 +214,26 @@ int rt_trace_any(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d
                  const float *tmax, uint8_t *occluded);
 /* How traversal maps rays to lanes. No counterpart in the reference (its CPU loop has no such choice); results
  * are identical under all settings, only the speed differs.
- *   RT_SCHEDULE_AUTO (default): LOCKSTEP for scenes whose traversal tables fit in LDS, STREAM otherwise.
+ *   RT_SCHEDULE_AUTO (default): for rt_trace_*, LOCKSTEP for scenes whose traversal tables fit in LDS, STREAM otherwise.
  *   RT_SCHEDULE_LOCKSTEP:       one ray per lane, a wave ends with its slowest ray. Fastest for coherent batches and
  *                               small scenes (cornellBox camera rays: 37 vs 23 G rays/s).
  *   RT_SCHEDULE_STREAM:         lanes pick up the next ray as soon as theirs ends. Fastest for incoherent rays and for
  *                               scenes in HBM (1 M-triangle soup, incoherent rays: 0.63 vs 0.36 G rays/s).
- * Applies to rt_trace_* and, for scenes in HBM, to the extend and shadow stages of rt_render. */
-enum { RT_OPTION_TRACE_SCHEDULE = 1, RT_OPTION_PIPELINES = 2 };
+ *   RT_SCHEDULE_REFILL:         lanes fetch and prepare their next ray themselves once enough of them are idle; no pool
+ *                               of prepared rays in LDS, so more waves stay resident than under STREAM. Fastest for the
+ *                               bounce rays of a scene in LDS (cornellBox: 9.6 vs 6.4 G rays/s in lockstep).
+ * Applies to rt_trace_* and, for scenes in HBM, to the extend and shadow stages of rt_render. On scenes in LDS rt_render's
+ * extend stage runs LOCKSTEP for camera rays and REFILL from the first bounce on, whatever the option says. */
+enum { RT_OPTION_TRACE_SCHEDULE = 1, RT_OPTION_PIPELINES = 2, RT_OPTION_KERNEL_TIMES = 3 };
 enum { RT_SCHEDULE_AUTO = 0, RT_SCHEDULE_LOCKSTEP = 1, RT_SCHEDULE_STREAM = 2, RT_SCHEDULE_REFILL = 3 };
 /* RT_OPTION_PIPELINES: how many passes of the wavefront path tracer overlap on separate streams (1..RT_MAX_PIPELINES,
  * default RT_MAX_PIPELINES). 1 runs the passes one after the other, which is how a single kernel's launch time is
  * measured without other passes sharing the CUs. Results do not depend on it. */
 enum { RT_MAX_PIPELINES = 3 };
+/* RT_OPTION_KERNEL_TIMES: 1 = rt_render / rt_render_dev record a HIP event before and after every extend and shade launch
+ * of a Path render, which rt_get_stats turns into extend_ms / shade_ms (and their launch counts); 0 (default) = no events
+ * in the render's streams, and those fields stay 0. A measurement times the job with 0 and reads launch times from a
+ * separate run with 1. */
 int rt_set_option(rt_context *ctx, int option, int value);
 
 /* Same, all pointers in device memory, asynchronous on the context's stream (call rt_synchronize). */

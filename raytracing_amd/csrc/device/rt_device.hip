@@ -104,6 +104,7 @@ struct rt_context {
     // first bounce whose extend / shadow stage runs the refilling kernels (scenes in LDS); experiments set them from the environment
     int refillExtendFrom = 1, refillShadowFrom = 1 << 30;
     int pipelines = RT_PIPES;   // RT_OPTION_PIPELINES
+    bool kernelTimes = false;   // RT_OPTION_KERNEL_TIMES: HIP events around the extend and shade launches of a Path render
     std::vector<EventPair> extendEvents, shadeEvents;   // HIP events around every extend / shade launch of the path tracer
     size_t extendEventsUsed = 0, shadeEventsUsed = 0;
     double renderMs = 0;
@@ -437,7 +438,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
             sppPass = (sppPass + 1) / 2;
         }
         if ((rc = ensure_spill(c))) return rc;
-        own = RenderScratch{c->pb, rt_context::kPipes, c->pbCapacity, c->dSpillRgb, c->dSpillW, c->dStats, true};
+        own = RenderScratch{c->pb, rt_context::kPipes, c->pbCapacity, c->dSpillRgb, c->dSpillW, c->dStats, c->kernelTimes};
     }
     const RenderScratch &rs = fixed ? *fixed : own;
     const bool stats = p->collect_stats != 0;
@@ -779,6 +780,10 @@ int render_group(rt_context *c, const rt_render_params *p, float *rgb, float *ws
             HIPCHK(c, hipStreamWaitEvent(c->stream, m->groupDone, 0));
             hipLaunchKernelGGL(k_add_floats, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, nPix * 4, c->dGroupFilm, (const float *)m->dGroupFilm);
         }
+        // the sums above read the peers' films on the root's stream: a peer's stream (whose next render clears its film)
+        // continues only after them
+        HIPCHK(c, hipEventRecord(c->groupDone, c->stream));
+        for (int k = 1; k < G; ++k) HIPCHK(c, hipStreamWaitEvent(members[k]->stream, c->groupDone, 0));
     }
     hipLaunchKernelGGL(k_add_floats, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, nPix * 3, rgb, (const float *)c->dGroupFilm);
     hipLaunchKernelGGL(k_add_floats, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, nPix, wsum, (const float *)(c->dGroupFilm + 3 * nPix));
@@ -1290,6 +1295,11 @@ static int set_option_one(rt_context *c, int option, int value) {
         c->pipelines = value;
         return RT_OK;
     }
+    if (option == RT_OPTION_KERNEL_TIMES) {
+        if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARG, "kernel times: 0 or 1");
+        c->kernelTimes = value != 0;
+        return RT_OK;
+    }
     return fail(c, RT_ERR_INVALID_ARG, "unknown option");
 }
 
@@ -1347,13 +1357,18 @@ int rt_create_multi(const int *device_ids, int n_devices, rt_context **out) {
     if (!out) { g_create_err = "out_ctx is NULL"; return RT_ERR_INVALID_ARG; }
     *out = nullptr;
     if (!device_ids || n_devices < 1 || n_devices > noalloc::kMaxDevices) { g_create_err = "bad device list"; return RT_ERR_INVALID_ARG; }
+    bool distinct = true, same = true;
+    for (int k = 0; k < n_devices; ++k) {
+        if (device_ids[k] != device_ids[0]) same = false;
+        for (int j = 0; j < k; ++j)
+            if (device_ids[k] == device_ids[j]) distinct = false;
+    }
+    // all different (one RCCL rank per GPU) or all the same (the one-GPU rehearsal, films summed on that device); a list that
+    // repeats some devices only would have the rehearsal's device-local sums read another GPU's memory
+    if (!distinct && !same) { g_create_err = "device list must name distinct devices, or one device repeatedly"; return RT_ERR_INVALID_ARG; }
     rt_context *root = nullptr;
     int rc = rt_create(device_ids[0], &root);
     if (rc) return rc;
-    bool distinct = true;
-    for (int k = 0; k < n_devices; ++k)
-        for (int j = 0; j < k; ++j)
-            if (device_ids[k] == device_ids[j]) distinct = false;
     for (int k = 1; k < n_devices; ++k) {
         rt_context *m = nullptr;
         if ((rc = rt_create(device_ids[k], &m))) { rt_destroy(root); return rc; }
@@ -1386,9 +1401,15 @@ int rt_create_multi(const int *device_ids, int n_devices, rt_context **out) {
 }
 
 void rt_shard_range(int spp_begin, int spp_end, int member, int n_members, int *out_begin, int *out_end) {
-    const long long total = (long long)spp_end - spp_begin;
-    *out_begin = spp_begin + (int)(member * total / n_members);
-    *out_end = spp_begin + (int)((member + 1) * total / n_members);
+    // bad arguments (no members, a member outside the group, an inverted range) give the empty range at spp_begin
+    long long b = spp_begin, e = spp_begin;
+    if (n_members > 0 && member >= 0 && member < n_members && spp_end >= spp_begin) {
+        const long long total = (long long)spp_end - spp_begin;
+        b = spp_begin + member * total / n_members;
+        e = spp_begin + (member + 1) * total / n_members;
+    }
+    if (out_begin) *out_begin = (int)b;
+    if (out_end) *out_end = (int)e;
 }
 
 int rt_device_count(const rt_context *c) { return c ? 1 + (int)c->peers.size() : 0; }
@@ -1443,7 +1464,10 @@ int rt_get_stats(rt_context *c, rt_stats *out) {
             out->rays_closest += s.rays_closest; out->rays_any += s.rays_any; out->camera_samples += s.camera_samples;
             out->n_interior += s.n_interior; out->n_leaf += s.n_leaf; out->n_leaf_idx += s.n_leaf_idx; out->n_tri_tests += s.n_tri_tests;
             out->counted_rays += s.counted_rays; out->extend_launches += s.extend_launches; out->extend_rays += s.extend_rays;
-            out->extend_ms += s.extend_ms; out->shade_launches += s.shade_launches; out->shade_ms += s.shade_ms;
+            out->shade_launches += s.shade_launches;
+            // kernel times: the slowest member's (the members run side by side); render_ms stays the root's host clock
+            out->extend_ms = std::max(out->extend_ms, s.extend_ms);
+            out->shade_ms = std::max(out->shade_ms, s.shade_ms);
         } else if (rc) c->err = m->err;
     }
     if (!c->peers.empty()) (void)hipSetDevice(c->device);

@@ -227,6 +227,10 @@ class Context:
         """How many passes of the wavefront path tracer overlap on separate streams (1..3)."""
         self._check(self._lib.rt_set_option(self._h, 2, int(n)))
 
+    def set_kernel_times(self, on):
+        """HIP events around the extend and shade launches of Path renders (stats: extend_ms, shade_ms); off by default."""
+        self._check(self._lib.rt_set_option(self._h, 3, 1 if on else 0))
+
     def develop(self, rgb_sum, weight_sum, film_scale=1.0):
         """Film sums (host arrays of the camera's size) -> (H, W, 3) uint8 sRGB image, computed on the device."""
         rgb_sum = np.ascontiguousarray(rgb_sum, np.float32)

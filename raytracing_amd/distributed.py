@@ -13,13 +13,9 @@ def shard_range(spp_total, rank, world_size):
     """Contiguous, balanced sample-index range [begin, end) of `rank`."""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
-    # the library's own rule (rt_shard_range), so that one process per GPU and one context over several GPUs
-    # (rt_create_multi) cut a job at the same sample indices
-    import ctypes as C
-    from .device import device_lib
-    b, e = C.c_int(), C.c_int()
-    device_lib().rt_shard_range(0, int(spp_total), int(rank), int(world_size), C.byref(b), C.byref(e))
-    return b.value, e.value
+    # the library's own rule (rt_shard_range; tests/test_abi.py pins the two as equal), in plain integers so that a rank
+    # without the device library (a CPU-only host in a gloo group) can still find its shard
+    return rank * spp_total // world_size, (rank + 1) * spp_total // world_size
 
 
 def reduce_film(rgb, weight, dst=0):
@@ -28,8 +24,13 @@ def reduce_film(rgb, weight, dst=0):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rgb, weight
-    dist.reduce(rgb, dst=dst, op=dist.ReduceOp.SUM)
-    dist.reduce(weight, dst=dst, op=dist.ReduceOp.SUM)
+    # one exchange step: rgb sums and weight sums travel as one packed buffer
+    import torch
+    packed = torch.cat([rgb.reshape(-1), weight.reshape(-1)])
+    dist.reduce(packed, dst=dst, op=dist.ReduceOp.SUM)
+    if dist.get_rank() == dst:
+        rgb.copy_(packed[:rgb.numel()].view_as(rgb))
+        weight.copy_(packed[rgb.numel():].view_as(weight))
     return rgb, weight
 
 

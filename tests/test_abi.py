@@ -139,6 +139,40 @@ def test_shard_rule_covers_every_job_exactly_once():
             assert at == end and max(sizes) - min(sizes) <= 1
     assert [shard_range(1024, k, 8) for k in range(8)] == [(128 * k, 128 * (k + 1)) for k in range(8)]
     assert [shard_range(10, k, 4) for k in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
+    # the Python rule (plain integers, no library needed) is the library's rule
+    for total in (0, 1, 7, 1000, 1024):
+        for g in (1, 3, 8, 64):
+            for k in range(g):
+                lib.rt_shard_range(0, total, k, g, C.byref(b), C.byref(e))
+                assert shard_range(total, k, g) == (b.value, e.value)
+
+
+def test_shard_range_with_bad_arguments_gives_the_empty_range():
+    """No members, a member outside the group or an inverted job: the empty range at spp_begin, no division by zero; a NULL
+    output pointer is skipped."""
+    from raytracing_amd.device import device_lib
+    lib = device_lib()
+    b, e = C.c_int(-7), C.c_int(-7)
+    for begin, end, k, g in ((5, 100, 0, 0), (5, 100, 0, -3), (5, 100, 4, 4), (5, 100, -1, 4), (100, 5, 0, 2)):
+        lib.rt_shard_range(begin, end, k, g, C.byref(b), C.byref(e))
+        assert (b.value, e.value) == (begin, begin)
+    lib.rt_shard_range(0, 10, 1, 2, None, C.byref(e))
+    assert e.value == 10
+    lib.rt_shard_range(0, 10, 1, 2, C.byref(b), None)
+    assert b.value == 5
+
+
+def test_a_device_list_that_repeats_only_some_devices_is_refused():
+    """rt_create_multi takes distinct devices (RCCL) or one device repeated (rehearsal); {0, 1, 0} is neither. The check comes
+    before any device is touched, so it runs without a GPU."""
+    from raytracing_amd.device import device_lib
+    lib = device_lib()
+    ctx = C.c_void_p()
+    for ids in ([0, 1, 0], [0, 1, 1], [2, 0, 2, 1]):
+        arr = (C.c_int * len(ids))(*ids)
+        rc = lib.rt_create_multi(arr, len(ids), C.byref(ctx))
+        assert rc == -1 and not ctx.value, ids   # RT_ERR_INVALID_ARG
+        assert b"distinct" in lib.rt_last_error(None)
 
 
 def test_rccl_offers_what_the_multi_gpu_context_binds():

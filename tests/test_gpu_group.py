@@ -58,3 +58,25 @@ def test_group_render_is_the_sum_of_its_shards(gpu_ctx, path_scene, members):
         a, aw = grp.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=2, spp=1, max_depth=3)
         b_, bw = gpu_ctx.render(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=2, spp=1, max_depth=3)
         assert np.array_equal(aw, bw) and np.array_equal(a, b_)
+
+
+def test_two_device_renders_back_to_back_on_a_group(gpu_ctx, path_scene):
+    """rt_render_dev returns once the work is queued: a second call right behind the first clears and refills the members'
+    packed films while the first call's sums may still be pending. Both films must come out as from the host entry point."""
+    import torch
+    from raytracing_amd.device import Context
+    cfg = path_scene.config.with_resolution(320, 240, spp=8)
+    kw = dict(integrator=RT_INTEGRATOR_PATH, rng_mode=RT_RNG_COUNTER, seed=4, spp=8, max_depth=15)
+    dev = torch.device("cuda", 0)
+    with Context(device_ids=[0, 0]) as grp:
+        grp.upload_scene(path_scene)
+        grp.set_camera(cfg)
+        want, want_w = grp.render(**kw)
+        films = [(torch.zeros((240, 320, 3), dtype=torch.float32, device=dev), torch.zeros((240, 320), dtype=torch.float32, device=dev)) for _ in range(3)]
+        torch.cuda.synchronize()
+        for rgb, w in films:
+            grp.render_dev(rgb.data_ptr(), w.data_ptr(), **kw)
+        grp.synchronize()
+        for rgb, w in films:
+            assert np.array_equal(w.cpu().numpy(), want_w)
+            assert np.array_equal(rgb.cpu().numpy(), want)
