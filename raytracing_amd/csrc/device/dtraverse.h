@@ -11,7 +11,7 @@
 #pragma once
 #include "dmath.h"
 
-#define RT_BLOCK 256
+#define RT_BLOCK 256   // threads per workgroup of every kernel: four waves (the block-wide appends and rings count on exactly four)
 #define RT_STACK_TOTAL 64     // the reference's todo[64]
 // todo entries per lane kept in LDS; the rest lives in private memory. Small (LDS-resident) scenes have
 // shallow trees, so a short LDS part keeps more workgroups resident per CU.

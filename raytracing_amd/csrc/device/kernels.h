@@ -231,6 +231,7 @@ RT_DEV uint64_t path_sequence(const CameraDev &cam, const PassInfo &ps, uint32_t
 // single atomicAdd for the whole 256-thread block, and every lane gets base + rank. All threads of the block must
 // call it (it synchronises). `lds` holds 16 dwords.
 RT_DEV void block_append2(uint32_t *lds, uint32_t *c0, uint32_t *c1, bool w0, bool w1, uint32_t &s0, uint32_t &s1) {
+    static_assert(RT_BLOCK == 256, "the per-wave counts below are summed over exactly four waves");
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -413,24 +414,39 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
     uint32_t *cntNext = &pb.counts[cnt_index(bounce + 1, 0)];
     uint32_t *cntShadow = &pb.counts[cnt_index(bounce, 1)];
     uint32_t *cntProbe = &pb.counts[cnt_index(bounce, 2)];
-    // Rays that missed have nothing to shade. The block reads hit records 256 at a time, keeps the slots of the hits
-    // in a ring in LDS and shades 256 of them at a time, so that (but for the block's last round) every lane has work.
+    // Rays that missed have nothing to shade. The block reads hit records and direction records 256 at a time, keeps those of
+    // the hits in a ring in LDS and shades 256 of them at a time, so that (but for the block's last round) every lane has
+    // work. The records of the next chunk are requested before a round's shading and put into the ring after it, so their
+    // memory round trip runs beside the shading instead of in front of it.
     __shared__ uint32_t s_fill[8];
     __shared__ uint32_t s_slot[2 * RT_BLOCK];
     __shared__ float4 s_hit[2 * RT_BLOCK];
+    __shared__ float4 s_rb[2 * RT_BLOCK];
     const uint32_t nChunks = (n + RT_BLOCK - 1u) / RT_BLOCK;
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     uint32_t chunk = blockIdx.x, head = 0, pending = 0, parity = 0;   // the same in every thread of the block
+    // the chunk on its way: requested, not yet in the ring
+    float4 hjP = make_float4(0.f, 0.f, 0.f, 0.f), rbP = hjP;
+    uint32_t jP = 0;
+    bool onTheWay = false;   // the same in every thread of the block
+    auto request = [&]() {
+        jP = chunk * RT_BLOCK + threadIdx.x;
+        chunk += gridDim.x;
+        hjP = rbP = make_float4(-0.f, 0.f, 0.f, 0.f);   // the sign bit of x: a record that is no hit
+        if (jP < n) {
+            hjP = pb.hit[jP];
+            rbP = pb.rayB[cur][jP];
+        }
+        onTheWay = true;
+    };
+    if (chunk < nChunks) request();
     for (;;) {
-        while (pending < RT_BLOCK && chunk < nChunks) {
-            const uint32_t j = chunk * RT_BLOCK + threadIdx.x;
-            chunk += gridDim.x;
-            float4 hj = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool isHit = false;
-            if (j < n) {
-                hj = pb.hit[j];
-                isHit = __float_as_int(hj.x) >= 0;
-            }
+        while (pending < RT_BLOCK && (onTheWay || chunk < nChunks)) {
+            if (!onTheWay) request();
+            const float4 hj = hjP, rbj = rbP;
+            const uint32_t j = jP;
+            onTheWay = false;
+            const bool isHit = __float_as_int(hj.x) >= 0;
             const unsigned long long m = __ballot(isHit);
             if (lane == 0) s_fill[parity * 4 + wave] = (uint32_t)__popcll(m);
             __syncthreads();
@@ -444,11 +460,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                 const uint32_t e = (head + pending + pre + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (2 * RT_BLOCK - 1u);
                 s_slot[e] = j;
                 s_hit[e] = hj;
+                s_rb[e] = rbj;
             }
             pending += total;
             parity ^= 1u;   // the next round's counts go to the other half: one barrier per round is enough
         }
         if (pending == 0) break;
+        if (chunk < nChunks) request();   // consumed after this round's shading
         const uint32_t take = pending < RT_BLOCK ? pending : RT_BLOCK;
         __syncthreads();   // ring entries written above are visible
         bool alive = false;   // set when the path continues
@@ -460,7 +478,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
             const uint32_t e = (head + threadIdx.x) & (2 * RT_BLOCK - 1u);
             const uint32_t i = s_slot[e];
             const float4 hr = s_hit[e];
-            const float4 rb = pb.rayB[cur][i];
+            const float4 rb = s_rb[e];
             // only a sphere hit needs the origin
             const float4 ra = SPH ? (bounce > 0 ? pb.rayA[cur][i] : camera_origin(cam)) : make_float4(0.f, 0.f, 0.f, 0.f);
             const uint32_t idBits = __float_as_uint(rb.w);
@@ -677,20 +695,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_stream(DevScene sc, PathBuf
     ShadowJob job = {pb.shA, pb.shB, pb.shC, pb.L};
     trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
                                                                        job, cn);
-    if (STATS) flush_counters(stats, cn, cn.rays);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
-}
-
-template <bool LDS_SCENE, bool STATS, bool SPH>
-__global__ __launch_bounds__(RT_BLOCK, RT_RF_MIN_BLOCKS) void k_shadow_refill(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
-    RT_DYNAMIC_LDS(smem);
-    const uint32_t n = pb.counts[cnt_index(bounce, 1)];
-    if (blockIdx.x * RT_BLOCK >= n) return;
-    SceneTables tb;
-    tables_setup<LDS_SCENE>(sc, smem, tb);
-    TravCounters cn = {0, 0, 0, 0, 0};
-    ShadowJob job = {pb.shA, pb.shB, pb.shC, pb.L};
-    trace_refill<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), n, job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }

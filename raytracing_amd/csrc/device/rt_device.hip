@@ -101,8 +101,11 @@ struct rt_context {
     unsigned long long *dStats = nullptr;
     int traceSchedule = RT_SCHEDULE_AUTO;
     size_t shadeLdsBytes = 0;   // dynamic LDS of k_shade when it shades out of a copy of the tables in LDS; 0 = tables in memory
-    // first bounce whose extend / shadow stage runs the refilling kernels (scenes in LDS); experiments set them from the environment
-    int refillExtendFrom = 1, refillShadowFrom = 1 << 30;
+    // Scenes in LDS: first bounce whose extend stage runs the refilling kernel. Camera rays are coherent and stay with the
+    // lockstep kernel (11.98 against 11.74 G rays/s with the refilling kernel from bounce 0, 11.57 from bounce 2); the shadow
+    // stage stays lockstep too: its rays are 0.9999 long, their cost is the set-up, which lockstep runs at full width
+    // (11.98 against 11.30 G rays/s with refilling shadow kernels).
+    int refillExtendFrom = 1;
     int pipelines = RT_PIPES;   // RT_OPTION_PIPELINES
     bool kernelTimes = false;   // RT_OPTION_KERNEL_TIMES: HIP events around the extend and shade launches of a Path render
     std::vector<EventPair> extendEvents, shadeEvents;   // HIP events around every extend / shade launch of the path tracer
@@ -509,9 +512,6 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
                 if (streamTrace) {
                     auto ks = RT_PICK(k_shadow_stream, c, stats);
                     hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, pb, b, rs.stats);
-                } else if (c->ldsScene && b >= c->refillShadowFrom) {
-                    auto ks = RT_PICK(k_shadow_refill, c, stats);
-                    hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, lds)), dim3(RT_BLOCK), lds, st, c->sc, pb, b, rs.stats);
                 } else {
                     auto ks = RT_PICK(k_shadow, c, stats);
                     hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, rs.stats);
@@ -835,8 +835,6 @@ int rt_create(int device_id, rt_context **out) {
 #define RT_GRID_BLOCKS_PER_CU 8   // persistent grids: workgroups per CU (grid-stride loops over the device-resident queue counters)
 #endif
     c->gridBlocks = c->numCUs * RT_GRID_BLOCKS_PER_CU;
-    if (const char *v = std::getenv("RT_EXP_REFILL_EXTEND_FROM")) c->refillExtendFrom = std::atoi(v);
-    if (const char *v = std::getenv("RT_EXP_REFILL_SHADOW_FROM")) c->refillShadowFrom = std::atoi(v);
     if ((e = scratch_address(device_id, &c->scratchPtr)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int k = 0; k < rt_context::kPipes; ++k) {
@@ -1045,7 +1043,6 @@ static int upload_scene_one(rt_context *c, const rt_scene_desc *d) {
     {
         const size_t bytes = 16 * (size_t)shade_tables_vecs(d->n_prims, d->n_materials, d->n_lights, d->n_spheres);
         c->shadeLdsBytes = (d->n_prims < (1u << 16) && bytes <= 16384) ? bytes : 0;
-        if (const char *v = std::getenv("RT_EXP_SHADE_LDS")) if (v[0] == '0') c->shadeLdsBytes = 0;
     }
     for (int k = 0; k < 3; ++k) { sc.bmin[k] = d->bounds[k]; sc.bmax[k] = d->bounds[3 + k]; }
     sc.nNodes = d->n_nodes;

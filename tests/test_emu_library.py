@@ -126,13 +126,21 @@ def test_session_one_device(emu, path_scene, scene_name):
     assert rgb8.shape == (H, W, 3) and rgb8.max() > 40
 
 
-@pytest.mark.parametrize("device_ids", [(0, 0), (0, 1), (1, 0, 1)])
+def test_a_device_list_that_repeats_some_devices_is_refused():
+    """(1, 0, 1) names a device twice among three members: neither RCCL's case (distinct devices) nor the rehearsal's (one
+    device throughout), where device-local sums would read another GPU's memory. rt_create_multi says so."""
+    if build_server() is None:
+        pytest.skip("no g++")
+    with pytest.raises(EmuError, match="distinct"):
+        EmuContext(device_ids=(1, 0, 1))
+
+
+@pytest.mark.parametrize("device_ids", [(0, 0), (0, 1), (1, 1, 1)])
 def test_group_of_members(device_ids):
-    """rt_create_multi. The device listed twice: members' films summed by a kernel on that device. Distinct devices: the
-    RCCL branch - communicator from ncclCommInitAll, one ncclReduce per member inside a group, on the member's stream -
-    against tests/emu/rccl/rccl.h, which gives the six entry points the library binds the semantics of a sum-reduce to rank
-    0. (1, 0, 1) names a device twice among three members: RCCL refuses that list, and so must rt_create_multi... by falling
-    back to the device-local sums. A tile-stream Whitted job (member 0 alone, allocates) sits between two group jobs."""
+    """rt_create_multi. One device listed two or three times: members' films summed by a kernel on that device. Distinct
+    devices: the RCCL branch - communicator from ncclCommInitAll, one ncclReduce per member inside a group, on the member's
+    stream - against tests/emu/rccl/rccl.h, which gives the six entry points the library binds the semantics of a sum-reduce
+    to rank 0. A tile-stream Whitted job (member 0 alone, allocates) sits between two group jobs."""
     from raytracing_amd.scene import FlatScene
     if build_server() is None:
         pytest.skip("no g++")
