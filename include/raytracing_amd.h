@@ -214,14 +214,16 @@ int rt_trace_any(rt_context *ctx, uint64_t n, const float *o_xyz, const float *d
                  const float *tmax, uint8_t *occluded);
 /* How traversal maps rays to lanes. No counterpart in the reference (its CPU loop has no such choice); results
  * are identical under all settings, only the speed differs.
- *   RT_SCHEDULE_AUTO (default): for rt_trace_*, LOCKSTEP for scenes whose traversal tables fit in LDS, STREAM otherwise.
+ *   RT_SCHEDULE_AUTO (default): LOCKSTEP for scenes whose traversal tables fit in LDS, REFILL otherwise.
  *   RT_SCHEDULE_LOCKSTEP:       one ray per lane, a wave ends with its slowest ray. Fastest for coherent batches and
  *                               small scenes (cornellBox camera rays: 37 vs 23 G rays/s).
  *   RT_SCHEDULE_STREAM:         lanes pick up the next ray as soon as theirs ends. Fastest for incoherent rays and for
  *                               scenes in HBM (1 M-triangle soup, incoherent rays: 0.63 vs 0.36 G rays/s).
  *   RT_SCHEDULE_REFILL:         lanes fetch and prepare their next ray themselves once enough of them are idle; no pool
- *                               of prepared rays in LDS, so more waves stay resident than under STREAM. Fastest for the
- *                               bounce rays of a scene in LDS (cornellBox: 9.6 vs 6.4 G rays/s in lockstep).
+ *                               of prepared rays in LDS, so more waves stay resident than under STREAM (6 against 4 per
+ *                               SIMD on scenes in HBM). Fastest for the bounce rays of a scene in LDS (cornellBox: 9.6 vs
+ *                               6.4 G rays/s in lockstep) and on scenes in HBM (4 M-triangle mesh, incoherent rays: 1.55 vs
+ *                               1.31 G rays/s streaming).
  * Applies to rt_trace_* and, for scenes in HBM, to the extend and shadow stages of rt_render. On scenes in LDS rt_render's
  * extend stage runs LOCKSTEP for camera rays and REFILL from the first bounce on, whatever the option says. */
 enum { RT_OPTION_TRACE_SCHEDULE = 1, RT_OPTION_PIPELINES = 2, RT_OPTION_KERNEL_TIMES = 3 };

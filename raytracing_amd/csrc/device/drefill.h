@@ -21,6 +21,12 @@
 #ifndef RT_RF_T_MAJ
 #define RT_RF_T_MAJ 24        // keep testing primitives while at least this many lanes have leaf primitives left
 #endif
+#ifndef RT_RF_D_MAJ_HBM
+#define RT_RF_D_MAJ_HBM 16    // tables in HBM: a node step costs a memory round trip however few lanes take it (see dstream.h)
+#endif
+#ifndef RT_RF_T_MAJ_HBM
+#define RT_RF_T_MAJ_HBM 16
+#endif
 #ifndef RT_RF_REFILL_MIN
 #define RT_RF_REFILL_MIN 12   // idle lanes needed before they fetch new rays (the set-up code costs the same for 1 lane as for 64)
 #endif
@@ -153,7 +159,7 @@ RT_DEV void trace_refill(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                     }
                 }
             }
-            if ((uint32_t)__popcll(RT_BALLOT(left == 0)) < RT_RF_D_MAJ) break;
+            if ((uint32_t)__popcll(RT_BALLOT(left == 0)) < (PERM ? RT_RF_D_MAJ : RT_RF_D_MAJ_HBM)) break;   // PERM: tables in LDS
         }
         // test: one primitive per lane and round; more rounds while enough of the wave is inside leaves
         for (;;) {
@@ -193,7 +199,7 @@ RT_DEV void trace_refill(const DevScene &sc, const SceneTables &tb, uint32_t *ld
                 }
                 if (left == 0 && !pop()) finish();
             }
-            if ((uint32_t)__popcll(RT_BALLOT(left > 0)) < RT_RF_T_MAJ) break;
+            if ((uint32_t)__popcll(RT_BALLOT(left > 0)) < (PERM ? RT_RF_T_MAJ : RT_RF_T_MAJ_HBM)) break;
         }
     }
 }

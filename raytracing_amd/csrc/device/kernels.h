@@ -507,7 +507,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                     L4.x += add.x; L4.y += add.y; L4.z += add.z;
                     Ldirty = true;
                 }
-                if (bounce < ps.maxDepth) {
+#ifndef RT_EXP_SHADE_PARTS   // timing builds only (results wrong, every access stays in bounds): bit 0 no scattering at all, bit 1 no light sampling
+#define RT_EXP_SHADE_PARTS 0
+#endif
+                if (!(RT_EXP_SHADE_PARTS & 1) && bounce < ps.maxDepth) {
                     DBsdf bs;
                     bsdf_init<MATSET>(bs, sf, sc.mats[sf.mat]);
                     Pcg rng;
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                     }
                     const f3 isectWo = normalize3(-rd);
 
-                    if (bsdf_num(bs, BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.nLights > 0) {
+                    if (!(RT_EXP_SHADE_PARTS & 2) && bsdf_num(bs, BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.nLights > 0) {
                         // uniformSampleOneLight
                         float selPdf;
                         const int li = sample_light(sc, pcg_float(rng), selPdf);
@@ -695,6 +698,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_stream(DevScene sc, PathBuf
     ShadowJob job = {pb.shA, pb.shB, pb.shC, pb.L};
     trace_stream<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), smem + stack_lds_bytes<LDS_SCENE>() / 16, n,
                                                                        job, cn);
+    if (STATS) flush_counters(stats, cn, cn.rays);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
+}
+
+// Refilling flavour of k_shadow (drefill.h), for scenes in HBM; on scenes in LDS the lockstep k_shadow is faster (the rays
+// are 0.9999 long and their cost is the set-up, which lockstep runs at full width).
+template <bool LDS_SCENE, bool STATS, bool SPH>
+__global__ __launch_bounds__(RT_BLOCK, RT_RF_MIN_BLOCKS) void k_shadow_refill(DevScene sc, PathBuffers pb, int bounce, unsigned long long *stats) {
+    RT_DYNAMIC_LDS(smem);
+    const uint32_t n = pb.counts[cnt_index(bounce, 1)];
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    SceneTables tb;
+    tables_setup<LDS_SCENE>(sc, smem, tb);
+    TravCounters cn = {0, 0, 0, 0, 0};
+    ShadowJob job = {pb.shA, pb.shB, pb.shC, pb.L};
+    trace_refill<false, STATS, StackCfg<LDS_SCENE>::LDS_N, LDS_SCENE, SPH>(sc, tb, reinterpret_cast<uint32_t *>(smem), n, job, cn);
     if (STATS) flush_counters(stats, cn, cn.rays);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ST_RAYS_ANY], (unsigned long long)n);
 }

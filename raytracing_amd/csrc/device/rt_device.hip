@@ -344,9 +344,14 @@ void launch_refill(rt_context *c, K k, uint64_t n, Args... args) {
     hipLaunchKernelGGL(k, dim3(grid), dim3(RT_BLOCK), lds, c->stream, args...);
 }
 
-bool use_stream_schedule(const rt_context *c) {
-    return c->traceSchedule == RT_SCHEDULE_STREAM || (c->traceSchedule == RT_SCHEDULE_AUTO && !c->ldsScene);
+// The schedule in force: RT_SCHEDULE_AUTO is lockstep for scenes in LDS and refilling for scenes in HBM (measured on the
+// 1 M-triangle soup and the 4 M-triangle mesh against streaming: camera rays 1.90 / 1.66 and 1.12 / 1.01 G rays/s, incoherent
+// rays 0.74 / 0.73 and 1.55 / 1.31, path tracing 536 / 489 and 717 / 646 M samples/s).
+int schedule_in_force(const rt_context *c) {
+    if (c->traceSchedule != RT_SCHEDULE_AUTO) return c->traceSchedule;
+    return c->ldsScene ? RT_SCHEDULE_LOCKSTEP : RT_SCHEDULE_REFILL;
 }
+bool use_stream_schedule(const rt_context *c) { return schedule_in_force(c) == RT_SCHEDULE_STREAM; }
 
 // The streaming kernels index rays with 32 bits: larger batches are cut into several launches.
 constexpr uint64_t kMaxRaysPerLaunch = 1ull << 31;
@@ -358,7 +363,7 @@ int trace_closest_dev(rt_context *c, uint64_t n, const float *o, const float *d,
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
         int32_t *prim_ = prim ? prim + base : nullptr;
         float *t_ = t ? t + base : nullptr, *bary_ = bary ? bary + 3 * base : nullptr;
-        if (c->traceSchedule == RT_SCHEDULE_REFILL) {
+        if (schedule_in_force(c) == RT_SCHEDULE_REFILL) {
             launch_refill(c, RT_PICK(k_trace_closest_refill, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
         } else if (use_stream_schedule(c)) {
             launch_stream(c, RT_PICK(k_trace_closest_stream, c, stats), m, c->sc, m, o_, d_, tm_, prim_, t_, bary_, c->dStats);
@@ -374,7 +379,7 @@ int trace_any_dev(rt_context *c, uint64_t n, const float *o, const float *d, con
     for (uint64_t base = 0; base < n; base += kMaxRaysPerLaunch) {
         const uint64_t m = std::min<uint64_t>(kMaxRaysPerLaunch, n - base);
         const float *o_ = o + 3 * base, *d_ = d + 3 * base, *tm_ = tmax ? tmax + base : nullptr;
-        if (c->traceSchedule == RT_SCHEDULE_REFILL) {
+        if (schedule_in_force(c) == RT_SCHEDULE_REFILL) {
             launch_refill(c, RT_PICK(k_trace_any_refill, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
         } else if (use_stream_schedule(c)) {
             launch_stream(c, RT_PICK(k_trace_any_stream, c, stats), m, c->sc, m, o_, d_, tm_, occ + base, c->dStats);
@@ -452,6 +457,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
     // overlap still wins (1080p, passes of 32 spp: +10 % on the 1 M-triangle soup, +8 % on the 4 M-triangle mesh), because
     // the late bounces of a pass are a few latency-bound launches that leave the device idle
     const bool streamTrace = use_stream_schedule(c);
+    const bool refillTrace = schedule_in_force(c) == RT_SCHEDULE_REFILL && !c->ldsScene;   // scenes in HBM: every bounce, and the shadow stage
     const int pipesInUse = std::min(c->pipelines, rs.nPipes);
 
     // what camera_origin() returns on the device: xf_apply(c2w, (0, 0, 0), 1) with the same operation order
@@ -490,7 +496,7 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
                 auto kx = RT_PICK(k_extend_stream, c, stats);
                 hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, originsOf(b),
                                    (const float4 *)pb.rayB[cur], pb.hit, (const uint32_t *)&pb.counts[cnt_index(b, 0)], rs.stats, camOrigin);
-            } else if (c->ldsScene && b >= c->refillExtendFrom) {
+            } else if (refillTrace || (c->ldsScene && b >= c->refillExtendFrom)) {
                 auto kx = RT_PICK(k_extend_refill, c, stats);
                 hipLaunchKernelGGL(kx, dim3(resident_grid(c, kx, lds)), dim3(RT_BLOCK), lds, st, c->sc, originsOf(b), (const float4 *)pb.rayB[cur], pb.hit,
                                    (const uint32_t *)&pb.counts[cnt_index(b, 0)], rs.stats, camOrigin);
@@ -512,6 +518,9 @@ int render_path(rt_context *c, const rt_render_params *p, float *rgb, float *wsu
                 if (streamTrace) {
                     auto ks = RT_PICK(k_shadow_stream, c, stats);
                     hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, ldsStream)), dim3(RT_BLOCK), ldsStream, st, c->sc, pb, b, rs.stats);
+                } else if (refillTrace) {
+                    auto ks = RT_PICK(k_shadow_refill, c, stats);
+                    hipLaunchKernelGGL(ks, dim3(resident_grid(c, ks, lds)), dim3(RT_BLOCK), lds, st, c->sc, pb, b, rs.stats);
                 } else {
                     auto ks = RT_PICK(k_shadow, c, stats);
                     hipLaunchKernelGGL(ks, dim3(grid), dim3(RT_BLOCK), lds, st, c->sc, pb, b, rs.stats);
@@ -1061,6 +1070,8 @@ static int upload_scene_one(rt_context *c, const rt_scene_desc *d) {
     (void)resident_grid(c, RT_PICK(k_shadow_stream, c, false), stream_lds_bytes_of(c));
     (void)resident_grid(c, RT_PICK(k_extend_refill, c, false), trace_lds_bytes(c));
     (void)resident_grid(c, RT_PICK(k_extend_refill, c, true), trace_lds_bytes(c));
+    (void)resident_grid(c, RT_PICK(k_shadow_refill, c, false), trace_lds_bytes(c));
+    (void)resident_grid(c, RT_PICK(k_shadow_refill, c, true), trace_lds_bytes(c));
     return RT_OK;
 }
 
