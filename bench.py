@@ -49,22 +49,23 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 # counters cannot be read inside a timed run, so the per-ray figures measured under the profiler are scaled by this run's
 # own ray counts and HIP-event times.
 PMC = {
-    "source": "profiles/r02_pmc_bench_steps4.md",
-    # HBM-side bytes per ray of k_extend: 2 x 13.5 B read (gfx950's FETCH_SIZE counts 16-B-per-lane coalesced reads at
-    # half their bytes; camera rays have no origin record) + 17.0 B written
-    "extend_hbm_bytes_per_ray": 44.0,
-    "extend_lanes_active": 12.6,            # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, of 64
-    "extend_lds_conflict_cycles": 0.39,     # SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS
-    "shade_hbm_bytes_per_path": 128.0,      # k_shade: (FETCH_SIZE x 2 + WRITE_SIZE) per ray entering the kernel
-    "shade_lanes_active": 54.3,
-    "extend_valu_per_ray": 56.6,            # SQ_INSTS_VALU per ray of the refilling kernel on third-bounce rays (lockstep: 88.9)
-    "valu_source": "profiles/r03_refill_compact_trace_bench.txt",
+    "source": "profiles/r03_pmc_bench_steps4.md",
+    # HBM-side bytes per extend ray, launches weighted by their rays (FETCH_SIZE doubled: gfx950 counts 16-B-per-lane coalesced
+    # reads at half their bytes): camera rays (lockstep kernel, no origin records) 16 B read + 16 B written; bounce rays
+    # (refilling kernel) 31 B read + 30 B written - a lane stores its hit record when its ray ends, so those 16-byte stores
+    # are not coalesced
+    "extend_hbm_bytes_per_ray": 50.0,
+    "extend_lanes_active": 18.8,            # refilling kernel: SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, of 64 (camera rays in lockstep: 42.1)
+    "extend_lds_conflict_cycles": 1.51,     # refilling kernel: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS (lanes stand in different leaves)
+    "extend_valu_per_ray": 51.5,            # refilling kernel on the pipeline's own bounce rays: SQ_INSTS_VALU per ray (lockstep, round 2: 61.5 over all bounces)
+    "shade_hbm_bytes_per_path": 109.0,      # k_shade: (FETCH_SIZE x 2 + WRITE_SIZE) per ray entering the kernel
+    "shade_lanes_active": 54.4,
 }
 PMC_SOUP = {
-    "source": "profiles/r02_soup_tuned_pmc_incoherent.md",
-    "fetch_bytes_per_ray_raw": 4067.0,      # FETCH_SIZE per ray (64 B per request, no correction: 8-byte gathers)
-    "l2_hit_rate": 0.50,
-    "lanes_active": 21.6,
+    "source": "profiles/r03_soup_refill_pmc_incoherent.md",
+    "fetch_bytes_per_ray_raw": 4232.0,      # FETCH_SIZE per ray (64 B per request, no correction: 8-byte gathers)
+    "l2_hit_rate": 0.53,
+    "lanes_active": 17.4,
 }
 
 
@@ -162,7 +163,7 @@ def soup_secondary(torch, dev, base_cfg, with_cpu):
             "Mrays_per_s": n_rays / (ms * 1e-3) / 1e6,
             "hit_fraction": float((prim >= 0).float().mean()),
             "roofline": {
-                "kernel": "k_trace_closest_stream (the traversal of k_extend_stream on a caller's batch)",
+                "kernel": "k_trace_closest_refill (the traversal of k_extend_refill on a caller's batch)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -273,6 +274,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1 M-triangle soup (BASELINE configs[3])")
     ap.add_argument("--no-strong", action="store_true", help="skip the 1024-spp strong-scaling job")
+    ap.add_argument("--no-c1", action="store_true", help="skip the 800x800 x 512 spp job (BASELINE configs[0]) that is timed against the reference")
     args = ap.parse_args(argv)
     pl = plan(args.gpus, os.environ)   # decided before anything touches a GPU
     mode, world, rank, local_rank = pl["mode"], pl["world"], pl["rank"], pl["local_rank"]
@@ -493,7 +495,8 @@ def main(argv=None):
                           "carries no events); three passes share the CUs as they do there",
                 "per_ray": {"interior": ni, "leaf": nl, "leaf_idx": nidx, "tri_tests": ntri},
                 "lanes_active_pmc": PMC["extend_lanes_active"],
-                "vector_instructions_per_ray_pmc": PMC["extend_valu_per_ray"],
+                "vector_instructions_per_bounce_ray_pmc": PMC["extend_valu_per_ray"],
+                "lds_bank_conflict_share_pmc": PMC["extend_lds_conflict_cycles"],
                 "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "bytes_per_ray_pmc": PMC["extend_hbm_bytes_per_ray"], "bytes_per_ray_unavoidable": 41.7},
                 "lds": {"bytes_per_ray_algorithmic": bpr - 44.0, "achieved_GBs": (bpr - 44.0) * ext_rays / ext_s / 1e9,
@@ -538,7 +541,7 @@ def main(argv=None):
                                      "note": "one 1024-spp job split by sample index over the GPUs, film reduce included; max over ranks"}
         if world == 1 and not args.no_secondary:
             out["secondary"] = soup_secondary(torch, dev, scene.config, with_cpu=not args.no_cpu_baseline)
-        if world == 1:
+        if world == 1 and not args.no_c1:
             out["gpu_over_reference_cpu_c1"] = c1_job(torch, dev, scene)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cfg)

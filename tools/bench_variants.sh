@@ -17,7 +17,7 @@ for CFG in "$@"; do
   ENVS=("RT_AMD_DEVICE_LIB=$LIB")
   for P in "${PARTS[@]:1}"; do ENVS+=("$P"); done
   F=$OUT/$(echo "$CFG" | tr ',=' '__').json
-  env "${ENVS[@]}" timeout -k 10 200 python3 $R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-secondary --no-strong > $F 2> $F.err || { echo "$CFG FAILED"; tail -3 $F.err; exit 1; }
+  env "${ENVS[@]}" timeout -k 10 200 python3 $R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-secondary --no-strong --no-c1 > $F 2> $F.err || { echo "$CFG FAILED"; tail -3 $F.err; exit 1; }
   python3 - "$CFG" $F <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

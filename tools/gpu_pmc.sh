@@ -3,7 +3,7 @@
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass). usage: [PROG=tools/trace_bench.py] tools/gpu_pmc.sh <tag> [program args...]
 set -o pipefail
 TAG=${1:-pmc}; shift
-ARGS=${@:---steps 4 --warmup 0 --no-cpu-baseline --no-secondary --no-strong}
+ARGS=${@:---steps 4 --warmup 0 --no-cpu-baseline --no-secondary --no-strong --no-c1}
 R=$GRAFT_REPO_ROOT
 PROG=${PROG:-bench.py}
 OUT=$R/gpurun_out/${TAG}

@@ -12,10 +12,10 @@ timeout -k 10 300 python -u $R/bench.py --steps 32 --warmup 1 --no-cpu-baseline 
 python3 -c "
 import json,sys
 d=json.load(open('$R/gpurun_out/${TAG}_bench.json'))
-print('Mrays/s %.1f  Msamples/s %.1f  ms/step %.3f  extend avg ms %.4f share %.3f' % (d['value'], d['samples_per_sec']/1e6, d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['extend_share_of_step']))"
+print('Mrays/s %.1f  Msamples/s %.1f  ms/step %.3f  extend avg ms %.4f' % (d['value'], d['samples_per_sec']/1e6, d['ms_per_step'], d['roofline']['avg_launch_ms']))"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${TAG}_prof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o prof -- python3 $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-secondary --no-strong > $R/gpurun_out/${TAG}_prof.log 2>&1 || { echo PROF FAILED; tail -5 $R/gpurun_out/${TAG}_prof.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o prof -- python3 $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-secondary --no-strong --no-c1 > $R/gpurun_out/${TAG}_prof.log 2>&1 || { echo PROF FAILED; tail -5 $R/gpurun_out/${TAG}_prof.log; exit 1; }
 python3 $R/tools/prof_summary.py $R/gpurun_out/${TAG}_prof/prof_results.db | head -14
 python3 - <<PY
 import sqlite3
