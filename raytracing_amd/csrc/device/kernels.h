@@ -507,10 +507,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                     L4.x += add.x; L4.y += add.y; L4.z += add.z;
                     Ldirty = true;
                 }
-#ifndef RT_EXP_SHADE_PARTS   // timing builds only (results wrong, every access stays in bounds): bit 0 no scattering at all, bit 1 no light sampling
-#define RT_EXP_SHADE_PARTS 0
-#endif
-                if (!(RT_EXP_SHADE_PARTS & 1) && bounce < ps.maxDepth) {
+                if (bounce < ps.maxDepth) {
                     DBsdf bs;
                     bsdf_init<MATSET>(bs, sf, sc.mats[sf.mat]);
                     Pcg rng;
@@ -530,7 +527,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_MIN_BLOCKS) void k_shade(DevScen
                     }
                     const f3 isectWo = normalize3(-rd);
 
-                    if (!(RT_EXP_SHADE_PARTS & 2) && bsdf_num(bs, BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.nLights > 0) {
+                    if (bsdf_num(bs, BSDF_ALL & ~BSDF_SPECULAR) > 0 && sc.nLights > 0) {
                         // uniformSampleOneLight
                         float selPdf;
                         const int li = sample_light(sc, pcg_float(rng), selPdf);
