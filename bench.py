@@ -60,7 +60,15 @@ PMC = {
     "extend_valu_per_ray": 51.5,            # refilling kernel on the pipeline's own bounce rays: SQ_INSTS_VALU per ray (lockstep, round 2: 61.5 over all bounces)
     "shade_hbm_bytes_per_path": 109.0,      # k_shade: (FETCH_SIZE x 2 + WRITE_SIZE) per ray entering the kernel
     "shade_lanes_active": 54.4,
+    "valu_per_camera_sample": 168.1,        # SQ_INSTS_VALU of every kernel of the run / camera samples (599.3 M: nine 32-spp passes and one of 1 spp)
 }
+# Cycles a SIMD needs to issue one wave64 vector instruction with two or more waves resident (tools/valu_rate.hip,
+# profiles/r03_valu_issue_rates.txt): 2.2 for plain two-operand f32 / integer instructions on VGPRs, 4.1 for fma, min / max,
+# compares, conversions, packed and f64 instructions and anything with an SGPR operand. 45 % of the hot loops' instructions
+# are of the first kind (ISA of k_extend_refill).
+ISSUE_CYCLES_MIX = 0.45 * 2.2 + 0.55 * 4.1
+ISSUE_CYCLES_SLOW = 4.1
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 PMC_SOUP = {
     "source": "profiles/r03_soup_refill_pmc_incoherent.md",
     "fetch_bytes_per_ray_raw": 4232.0,      # FETCH_SIZE per ray (64 B per request, no correction: 8-byte gathers)
@@ -503,15 +511,31 @@ def main(argv=None):
                         "note": "node, leaf-index and triangle bytes: served from LDS, not HBM traffic"},
                 "pmc_source": PMC["source"],
                 "note": "what binds is instruction issue under SIMD divergence (a wave issues every vector instruction for all 64 lanes "
-                        "whatever the number of live ones), so frac is the useful-flop fraction of the FP32 vector peak",
+                        "whatever the number of live ones), so frac is the useful-flop fraction of the FP32 vector peak; valu_issue is "
+                        "the roof the step actually runs against",
+                "valu_issue": {
+                    "scope": "all kernels of a step, one device (the job's samples / n_gpus)",
+                    "vector_instructions_per_camera_sample_pmc": PMC["valu_per_camera_sample"],
+                    "achieved": PMC["valu_per_camera_sample"] * samples / world / t / 1e9,
+                    "peak": SIMDS * CLOCK_HZ / ISSUE_CYCLES_MIX / 1e9,
+                    "unit": "G wave-instructions/s",
+                    "frac": PMC["valu_per_camera_sample"] * samples / world / t * ISSUE_CYCLES_MIX / (SIMDS * CLOCK_HZ),
+                    "frac_if_every_instruction_cost_4_1_cycles": PMC["valu_per_camera_sample"] * samples / world / t * ISSUE_CYCLES_SLOW / (SIMDS * CLOCK_HZ),
+                    "cycles_per_instruction": {"plain two-operand f32 / integer on VGPRs": 2.2, "fma, min / max, compare, convert, packed, f64, "
+                                               "any SGPR operand": 4.1, "rcp, sqrt": 8.1, "mix of the hot loops": ISSUE_CYCLES_MIX},
+                    "source": "profiles/r03_valu_issue_rates.txt (tools/valu_rate.hip), " + PMC["source"],
+                },
                 "launch_overlap": "durations include time shared with the kernels of two other passes (three pipelines); 'exclusive' is "
                                   "the same kernels on the same queues with the passes run one after the other",
             }
             out["roofline_shade"] = {
                 "kernel": "k_shade (one bounce of PathRenderer::Li per ray: NEE + MIS, BSDF sample, Russian roulette, queue appends)",
-                "bound": "latency",
-                "bound_note": "neither roof binds: 70 % of wave-cycles are spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) at 3 waves per SIMD "
-                              "(134 registers), 54 of 64 lanes live; the HBM figures below say how far the kernel is from the byte roof",
+                "bound": "valu-issue",
+                "bound_note": "large launches: a wave's round of 256 paths takes 19 k cycles, of which its SIMD spends 17 k issuing the ~1 380 "
+                              "shading instructions of its three waves at 4.1 cycles each (profiles/r03_shade_phase_stamps.txt, "
+                              "profiles/r03_valu_issue_rates.txt); the eleven small launches of a pass are latency-bound, which is what the "
+                              "70 % waiting of the counters' average shows. 54 of 64 lanes live. The HBM figures below say how far the "
+                              "kernel is from the byte roof",
                 "achieved": shade_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

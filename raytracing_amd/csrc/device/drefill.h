@@ -1,8 +1,9 @@
 // Refilling KD-tree tracer for scenes whose tables sit in LDS: the lane schedule of trace_stream (dstream.h) without its
 // pool of prepared rays and within the register and LDS budget of the lockstep kernels.
 //
-// The wavefront path tracer on a scene of a few kilobytes is bound by vector-instruction issue: every SIMD issues one every
-// cycle, so a kernel's cost is the number of wave-level instructions it issues, whatever the number of live lanes. kd_trace
+// The wavefront path tracer on a scene of a few kilobytes is bound by vector-instruction issue: a SIMD issues one wave-level
+// instruction every 2.2 - 4.1 cycles (tools/valu_rate.hip), whatever the number of live lanes, so a kernel's cost is the
+// number of wave-level instructions it issues. kd_trace
 // (dtraverse.h) issues ~90 of them per bounce ray with 11 of 64 lanes live, because a wave runs until its slowest ray ends
 // and every lane waits at every leaf for the lane with the biggest one. trace_stream cuts that to ~60, but its prepared-ray
 // pool (16 KB of LDS per workgroup) and 112 registers leave room for 4 waves per SIMD, and the instructions it saves are lost

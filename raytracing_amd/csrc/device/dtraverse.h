@@ -102,7 +102,7 @@ RT_DEV void ray_setup(RayCtx &r, f3 o, f3 d) {
     f3 dp = perm3(d, r.kz);
     r.Sx = -dp.x / dp.z;
     r.Sy = -dp.y / dp.z;
-    r.Sz = 1.f / dp.z;
+    r.Sz = comp3(r.invDir, r.kz);   // 1.f / dp.z, and dp.z is d's component kz: the quotient already computed for invDir
     r.op = perm3(o, r.kz);
 }
 
