@@ -516,11 +516,11 @@ def main(argv=None):
                 "valu_issue": {
                     "scope": "all kernels of a step, one device (the job's samples / n_gpus)",
                     "vector_instructions_per_camera_sample_pmc": PMC["valu_per_camera_sample"],
-                    "achieved": PMC["valu_per_camera_sample"] * samples / world / t / 1e9,
+                    "achieved": PMC["valu_per_camera_sample"] * samples / (1 if rehearsal else world) / t / 1e9,
                     "peak": SIMDS * CLOCK_HZ / ISSUE_CYCLES_MIX / 1e9,
                     "unit": "G wave-instructions/s",
-                    "frac": PMC["valu_per_camera_sample"] * samples / world / t * ISSUE_CYCLES_MIX / (SIMDS * CLOCK_HZ),
-                    "frac_if_every_instruction_cost_4_1_cycles": PMC["valu_per_camera_sample"] * samples / world / t * ISSUE_CYCLES_SLOW / (SIMDS * CLOCK_HZ),
+                    "frac": PMC["valu_per_camera_sample"] * samples / (1 if rehearsal else world) / t * ISSUE_CYCLES_MIX / (SIMDS * CLOCK_HZ),
+                    "frac_if_every_instruction_cost_4_1_cycles": PMC["valu_per_camera_sample"] * samples / (1 if rehearsal else world) / t * ISSUE_CYCLES_SLOW / (SIMDS * CLOCK_HZ),
                     "cycles_per_instruction": {"plain two-operand f32 / integer on VGPRs": 2.2, "fma, min / max, compare, convert, packed, f64, "
                                                "any SGPR operand": 4.1, "rcp, sqrt": 8.1, "mix of the hot loops": ISSUE_CYCLES_MIX},
                     "source": "profiles/r03_valu_issue_rates.txt (tools/valu_rate.hip), " + PMC["source"],
