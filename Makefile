@@ -9,7 +9,10 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -pthread
-HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function
+# -fno-slp-vectorize: the compiler pairs neighbouring float multiplies and adds into v_pk_mul_f32 / v_pk_add_f32, which a
+# SIMD issues in 4.1 cycles - what the two plain instructions take (2.2 each, tools/valu_rate.hip) - and pays register moves
+# to line the pairs up. Without it k_shade has 97 moves and 10 registers fewer; 12.7 -> 13.1 G rays/s on the cornellBox.
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function
 
 HOST_SRC = $(wildcard raytracing_amd/csrc/host/*.cpp)
 HOST_HDR = $(wildcard raytracing_amd/csrc/host/*.h) $(wildcard include/*.h)

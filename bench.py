@@ -49,7 +49,7 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 # counters cannot be read inside a timed run, so the per-ray figures measured under the profiler are scaled by this run's
 # own ray counts and HIP-event times.
 PMC = {
-    "source": "profiles/r03_pmc_bench_steps4.md",
+    "source": "profiles/r03_pmc_bench_steps4_noslp.md",
     # HBM-side bytes per extend ray, launches weighted by their rays (FETCH_SIZE doubled: gfx950 counts 16-B-per-lane coalesced
     # reads at half their bytes): camera rays (lockstep kernel, no origin records) 16 B read + 16 B written; bounce rays
     # (refilling kernel) 31 B read + 30 B written - a lane stores its hit record when its ray ends, so those 16-byte stores
@@ -57,16 +57,16 @@ PMC = {
     "extend_hbm_bytes_per_ray": 50.0,
     "extend_lanes_active": 18.8,            # refilling kernel: SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, of 64 (camera rays in lockstep: 42.1)
     "extend_lds_conflict_cycles": 1.51,     # refilling kernel: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS (lanes stand in different leaves)
-    "extend_valu_per_ray": 51.5,            # refilling kernel on the pipeline's own bounce rays: SQ_INSTS_VALU per ray (lockstep, round 2: 61.5 over all bounces)
+    "extend_valu_per_ray": 50.9,            # refilling kernel on the pipeline's own bounce rays: SQ_INSTS_VALU per ray (lockstep, round 2: 61.5 over all bounces)
     "shade_hbm_bytes_per_path": 109.0,      # k_shade: (FETCH_SIZE x 2 + WRITE_SIZE) per ray entering the kernel
     "shade_lanes_active": 54.4,
-    "valu_per_camera_sample": 168.1,        # SQ_INSTS_VALU of every kernel of the run / camera samples (599.3 M: nine 32-spp passes and one of 1 spp)
+    "valu_per_camera_sample": 167.5,        # SQ_INSTS_VALU of every kernel of the run / camera samples (599.3 M: nine 32-spp passes and one of 1 spp)
 }
 # Cycles a SIMD needs to issue one wave64 vector instruction with two or more waves resident (tools/valu_rate.hip,
 # profiles/r03_valu_issue_rates.txt): 2.2 for plain two-operand f32 / integer instructions on VGPRs, 4.1 for fma, min / max,
-# compares, conversions, packed and f64 instructions and anything with an SGPR operand. 45 % of the hot loops' instructions
-# are of the first kind (ISA of k_extend_refill).
-ISSUE_CYCLES_MIX = 0.45 * 2.2 + 0.55 * 4.1
+# compares, conversions, packed and f64 instructions and anything with an SGPR operand. 40 % of the instructions of the three
+# big kernels are of the first kind (static ISA: k_extend_refill 0.37, k_shade 0.47, k_shadow 0.29, weighted by their shares).
+ISSUE_CYCLES_MIX = 0.40 * 2.2 + 0.60 * 4.1
 ISSUE_CYCLES_SLOW = 4.1
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 PMC_SOUP = {

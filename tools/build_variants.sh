@@ -4,6 +4,6 @@ cd "$(dirname "$0")/.."
 mkdir -p build_exp
 while [ $# -ge 2 ]; do
   n=$1; f=$2; shift 2
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $f -shared -o build_exp/lib_$n.so raytracing_amd/csrc/device/rt_device.hip 2>&1 | grep -E "error" ; echo "built $n" ) &
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Wno-unused-function $f -shared -o build_exp/lib_$n.so raytracing_amd/csrc/device/rt_device.hip 2>&1 | grep -E "error" ; echo "built $n" ) &
 done
 wait
