@@ -346,6 +346,26 @@ int main(int argc, char **argv) {
     ROW(k_cmp_2mul_cndmask, float, 4)
     ROW(k_cndmask_sgpr, float, 1)
     ROW(k_s_nop, float, 1)
+    {   // the shader clock itself: cycles a wave counts against the time HIP events measure for the same launch
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        const int longIters = iters * 40;
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_fma, dim3(nCU * 2), dim3(1024), 0, 0, dOut, longIters, 1.0001f, 0.9999f, 0.5f);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        h.resize((size_t)nCU * 2 * 16);
+        CHECK(hipMemcpy(h.data(), dOut, sizeof(WaveRec) * h.size(), hipMemcpyDeviceToHost));
+        unsigned long long longest = 0;
+        for (const WaveRec &r : h) longest = std::max(longest, r.t1 - r.t0);
+        printf("# shader clock under this load (8 waves per SIMD of v_fma_f32): %.0f MHz (%llu cycles of the longest wave in a launch of %.3f ms)\n",
+               longest / (ms * 1e3), longest, ms);
+        CHECK(hipEventDestroy(e0));
+        CHECK(hipEventDestroy(e1));
+    }
     printf("# '*': some SIMD held more waves than that (two workgroups on one CU); the simd column divides by the waves found\n");
     CHECK(hipFree(dOut));
     return 0;
