@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 WIDTH, HEIGHT = 1920, 1080
-SPP_PER_STEP = int(os.environ.get("RT_BENCH_SPP_PER_STEP", "32"))
+SPP_PER_STEP = int(os.environ.get("RT_BENCH_SPP_PER_STEP", "64"))
 MAX_DEPTH = 15
 STRONG_SPP = 1024
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
@@ -189,7 +189,7 @@ def soup_secondary(torch, dev, base_cfg, with_cpu):
             },
         },
     }
-    # path tracing on the same scene: 16 spp is one pass; 128 spp is four passes of 32 spp that overlap on three pipelines
+    # path tracing on the same scene with the library's own pass sizes: three passes each, overlapping on three pipelines
     ctx.set_camera(cfg)
     ctx.set_kernel_times(True)   # these two jobs report launch times; their seconds include the (small) cost of the events
     rgb = torch.zeros((cfg.height, cfg.width, 3), dtype=torch.float32, device=dev)
@@ -338,9 +338,16 @@ def main(argv=None):
     rgb = film[:3 * npix].view(HEIGHT, WIDTH, 3)
     wsum = film[3 * npix:].view(HEIGHT, WIDTH)
 
-    def run(spp_begin, spp_end, total, collect=False):
+    def run(spp_begin, spp_end, total, collect=False, per_pass=P):
         ctx.render_dev(rgb.data_ptr(), wsum.data_ptr(), integrator=0, rng_mode=0, seed=1, spp=total, max_depth=MAX_DEPTH,
-                       spp_begin=spp_begin, spp_end=spp_end, spp_per_pass=P, collect_stats=collect)
+                       spp_begin=spp_begin, spp_end=spp_end, spp_per_pass=per_pass, collect_stats=collect)
+
+    def library_passes(spp_job):
+        """How rt_render cuts a job when spp_per_pass is 0: equal passes of at most 2^27 paths, a multiple of three of them."""
+        n = -(-spp_job // max(1, (1 << 27) // npix))
+        if n > 1 or (spp_job >= 3 and spp_job * npix >= 1 << 23):
+            n = -(-n // 3) * 3
+        return n
 
     def job(begin_of_rank0, per_gpu, total):
         """`per_gpu` samples per pixel on every GPU of a `total`-spp job, film summed on GPU 0: in ranks mode this rank's
@@ -393,17 +400,17 @@ def main(argv=None):
         ts = time.perf_counter()
         if mode == "ranks":
             sb, se = shard_range(STRONG_SPP, rank, world)
-            run(sb, se, STRONG_SPP)
+            run(sb, se, STRONG_SPP, per_pass=0)   # the library's own pass sizes
             ctx.synchronize()
             reduce_to_rank0(film)
         else:
             sb, se = shard_range(STRONG_SPP, 0, world)   # the library cuts the job by the same rule
-            run(0, STRONG_SPP, STRONG_SPP)
+            run(0, STRONG_SPP, STRONG_SPP, per_pass=0)
         fence()
         strong_elapsed = time.perf_counter() - ts
         sst = ctx.stats()
         strong = (strong_elapsed, float(sst["rays_closest"] + sst["rays_any"]), float(sst["camera_samples"]),
-                  float(wsum.min()) if rank == 0 else 0.0, -(-(se - sb) // P))
+                  float(wsum.min()) if rank == 0 else 0.0, library_passes(se - sb))
 
     # Kernel launch times, outside the timed region: the same steps once more with HIP events around the extend and shade
     # launches (three passes share the CUs, as in the timed region), then one step with the passes run one after the other

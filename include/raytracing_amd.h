@@ -118,8 +118,9 @@ typedef struct rt_render_params {
     float rr_threshold;    /* PathRenderer::m_rrThreshold, 1 in the reference (Render.cpp:322) */
     int32_t rng_mode;      /* RT_RNG_* */
     uint64_t seed;         /* COUNTER mode only */
-    int32_t spp_per_pass;  /* wavefront batch: samples per pixel in flight at once; 0 = library default (2^26 paths,
-                            * 272 B of queue state per path and pipeline) */
+    int32_t spp_per_pass;  /* wavefront batch: samples per pixel in flight at once; 0 = library default (the job cut into
+                            * equal passes of at most 2^27 paths, their number a multiple of the pipelines; 272 B of queue
+                            * state per path and pipeline; fewer paths if that much device memory is not free) */
     int32_t collect_stats; /* nonzero: count nodes / leaves / triangle tests per ray (slow path) */
 } rt_render_params;
 
