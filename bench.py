@@ -329,6 +329,8 @@ def main(argv=None):
         ctx = Context(local_dev)
     ctx.upload_scene(scene)
     ctx.set_camera(cfg)
+    PIPELINES = int(os.environ.get("RT_BENCH_PIPELINES", "3"))   # for comparisons; 3 is the library's default
+    ctx.set_pipelines(PIPELINES)
 
     K, W, P = args.steps, args.warmup, SPP_PER_STEP
     spp_total = world * K * P
@@ -432,7 +434,7 @@ def main(argv=None):
             if sx["extend_ms"] > 0:
                 exclusive = sx
         finally:
-            ctx.set_pipelines(3)
+            ctx.set_pipelines(PIPELINES)
             ctx.set_kernel_times(False)
     vals = [elapsed, float(st["rays_closest"] + st["rays_any"]), float(st["camera_samples"])]
     vals += list(strong[:3]) if strong else [0.0, 0.0, 0.0]
